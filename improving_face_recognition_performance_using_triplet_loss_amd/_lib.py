@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI declared in include/efm_hip.h.
+
+The HIP library is the ONLY compute path of this package: if `libefm_hip.so` is missing the import of
+anything that needs it raises (there is no torch / CPU fallback — the CPU oracle lives in `oracle/` and
+is test infrastructure only).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libefm_hip.so")
+
+EFM_OK = 0
+MFM_ORDER_GROUP = 0
+MFM_ORDER_RES = 1
+L2_ROW = 0
+L2_FROBENIUS = 1
+
+
+class EfmError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of `efm_conv_desc` (include/efm_hip.h)."""
+
+    _fields_ = [(n, c_int32) for n in (
+        "batch", "hin", "win", "cin", "cin_p", "hout", "wout", "cout", "cout_p",
+        "kh", "kw", "pad_h", "pad_w", "n_pad16", "k_pad", "dn_pad16", "dk_pad")]
+
+
+# name -> (restype, argtypes); the single source the symbol-export test checks against the header.
+SIGNATURES = {
+    "efm_version": (c_int, []),
+    "efm_last_error_string": (c_char_p, []),
+    "efm_conv_desc_init": (c_int, [POINTER(ConvDesc)] + [c_int] * 9),
+    "efm_conv_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_conv_dgrad_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "efm_conv_unpack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "efm_conv_make_dgrad_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "efm_conv_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 6),
+    "efm_conv_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
+    "efm_conv_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "efm_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_mfm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "efm_mfm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "efm_maxpool2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_maxpool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_triplet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "efm_triplet_bwd": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "efm_cosine_pairs": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "efm_gram_cosine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "efm_mine_semihard": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "efm_sgd_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),
+    "efm_adam_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises EfmError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EfmError(
+            "HIP extension %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != EFM_OK:
+        msg = load().efm_last_error_string()
+        raise EfmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def conv_desc(batch, hin, win, cin, cout, kh, kw, pad_h, pad_w):
+    d = ConvDesc()
+    check(load().efm_conv_desc_init(ctypes.byref(d), batch, hin, win, cin, cout, kh, kw, pad_h, pad_w), "efm_conv_desc_init")
+    return d
+
+
+def pad4(c):
+    return (c + 3) & ~3
+
+
+def pad16(c):
+    return (c + 15) & ~15

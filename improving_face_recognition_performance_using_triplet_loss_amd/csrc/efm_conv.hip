@@ -1,0 +1,633 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): forward / data-gradient / weight-gradient.
+//
+// Replaces mx.symbol.Convolution / nn.Conv2D / FullyConnected call sites of the reference
+// (efm_symbol.py:32,41,54,62,65,67,94; lightcnn.py:14-15,47-48,111) — the reference ships no
+// kernels of its own, MXNet dispatches these to cuDNN.
+//
+// Design (fp32 in, fp32 accumulate, exact: v_mfma_f32_16x16x4_f32):
+//   GEMM view  C[m][n] = sum_k A[m][k] * W[n][k]
+//     m = (b, ho, wo) output pixel, n = output channel, k = (kh, kw, ci) with ci fastest.
+//   A is never materialised: each 16-byte piece A[m][k..k+3] is 4 consecutive input channels
+//   of one NHWC pixel, fetched straight from x (zero outside the image = padding).
+//   Block = 256 threads = 4 waves; block tile = (64*MT) pixels x (16*NT) channels, K step 16.
+//   Each wave owns 16*MT pixel rows and all NT channel tiles -> MT*NT 16x16 accumulators.
+//   Operands are staged global -> registers -> LDS (double buffered, one barrier per K step);
+//   the LDS image is [row][16 floats] with the 16-byte slot XOR-swizzled so that both the
+//   staging ds_write_b128 and the fragment ds_read_b128 are bank-conflict free.
+//   One ds_read_b128 per lane feeds 4 MFMAs: lane (i = lane&15, q = lane>>4) holds
+//   A[i][4q..4q+3]; MFMA step j contracts k = {j, 4+j, 8+j, 12+j} on both operands.
+//   The data gradient is the same kernel run on dy with tap-flipped, transposed weights.
+//   The weight gradient contracts over pixels: C[n][k] = sum_m dy[m][n] * A[m][k], split over
+//   m into workspace slabs and reduced in a fixed order (bitwise reproducible).
+#include "efm_common.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ int swz_g(int b) { return (0x78 >> (2 * b)) & 3; }  // {0,2,3,1}
+
+struct ConvP {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  int M;
+  int hin, win, cin_p;
+  int hout, wout, cout_p;
+  int kh, kw, pad_h, pad_w;
+  int n_pad16, k_pad, ksteps;
+  int nblocks;
+};
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
+  constexpr int BM = MT * 64, BN = NT * 16;
+  constexpr int PB = (NT * 64 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware bijective remap: consecutive logical blocks (same pixel rows, neighbouring
+  // channel blocks / neighbouring pixel rows) share one XCD's L2.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int mb = lid / p.nblocks, nb = lid - mb * p.nblocks;
+  const int m0 = mb * BM, n0 = nb * BN;
+
+  // ---- staging coordinates: thread -> (row = tid/4 (+64 per pass), 16-byte piece kc = tid%4)
+  const int lrow = tid >> 2, kc = tid & 3;
+  int a_hi0[MT], a_wi0[MT];
+  long a_base[MT];
+  const int hw = p.hout * p.wout;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int m = m0 + lrow + 64 * j;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / hw, r = mm - b * hw;
+    const int ho = r / p.wout, wo = r - ho * p.wout;
+    a_hi0[j] = ok ? ho - p.pad_h : -(1 << 20);
+    a_wi0[j] = wo - p.pad_w;
+    a_base[j] = ((long)(b * p.hin + ho - p.pad_h) * p.win + (wo - p.pad_w)) * p.cin_p;
+  }
+  int c = kc * 4, kh_ = 0, kw_ = 0;
+  while (c >= p.cin_p) {
+    c -= p.cin_p;
+    if (++kw_ == p.kw) { kw_ = 0; ++kh_; }
+  }
+  const float* b_ptr[PB];
+  bool b_ok[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int brow = lrow + 64 * j;
+    const int n = n0 + brow;
+    b_ok[j] = (brow < BN) && (n < p.n_pad16);
+    b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * p.k_pad + kc * 4;
+  }
+
+  f32x4 ra[MT], rb[PB];
+  auto load_tile = [&](int t) {
+    const bool tap_ok = kh_ < p.kh;
+    const int doff = (kh_ * p.win + kw_) * p.cin_p + c;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int hi = a_hi0[j] + kh_, wi = a_wi0[j] + kw_;
+      const bool v = tap_ok && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + doff) : z;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rb[j] = b_ok[j] ? *reinterpret_cast<const f32x4*>(b_ptr[j] + t * 16) : z;
+    }
+    c += 16;
+    while (c >= p.cin_p) {
+      c -= p.cin_p;
+      if (++kw_ == p.kw) { kw_ = 0; ++kh_; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * (BM + BN) * 16;
+    float* Bs = As + BM * 16;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int row = lrow + 64 * j;
+      *reinterpret_cast<f32x4*>(As + (row * 4 + (kc ^ swz_g((row >> 2) & 3))) * 4) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int row = lrow + 64 * j;
+      if (row < BN) *reinterpret_cast<f32x4*>(Bs + (row * 4 + (kc ^ swz_g((row >> 2) & 3))) * 4) = rb[j];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fq = lane >> 4;
+  const int fsw = fq ^ swz_g(fi >> 2);
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * (BM + BN) * 16;
+    const float* Bs = As + BM * 16;
+    f32x4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = wave * (MT * 16) + mt * 16 + fi;
+      a[mt] = *reinterpret_cast<const f32x4*>(As + (row * 4 + fsw) * 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt += 2) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + ((nt * 16 + fi) * 4 + fsw) * 4);
+      f32x4 b1 = b0;
+      if (nt + 1 < NT) b1 = *reinterpret_cast<const f32x4*>(Bs + (((nt + 1) * 16 + fi) * 4 + fsw) * 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][jj], b0[jj], acc[mt][nt], 0, 0, 0);
+          if (nt + 1 < NT)
+            acc[mt][nt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][jj], b1[jj], acc[mt][nt + 1], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < p.ksteps; ++t) {
+    const bool more = t + 1 < p.ksteps;
+    if (more) load_tile(t + 1);
+    compute(t & 1);
+    if (more) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = 4*fq + r][col = fi] per 16x16 tile; + bias (+ residual)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 16 + fi;
+    if (n < p.cout_p) {
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wave * (MT * 16) + mt * 16 + fq * 4 + r;
+          if (m < p.M) {
+            const long off = (long)m * p.cout_p + n;
+            float v = acc[mt][nt][r] + bv;
+            if (p.res) v += p.res[off];
+            p.y[off] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient.  C[n][k] = sum_m dy[m][n] * A[m][k].  MFMA A operand = dy (rows = n),
+// B operand = im2col(x) (cols = k) so that a result register holds 16 consecutive k of one n
+// = 64 contiguous bytes of the packed gradient.  Block = 4 waves, each owning KPW k-tiles x NTW
+// n-tiles; 16 pixels per step (4 MFMA contractions of 4 pixels).
+// ------------------------------------------------------------------------------------------
+struct WgradP {
+  const float* x;
+  const float* dy;
+  float* ws;
+  int M;
+  int hin, win, cin_p;
+  int hout, wout, cout_p;
+  int kh, kw, pad_h, pad_w;
+  int n_pad16, k_pad;
+  int kblocks, nblocks, splits;
+  int m_per_split;
+};
+
+template <int KPW, int NTW>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
+  constexpr int BKR = 64 * KPW, BNW = 16 * NTW, BP = 16;
+  constexpr int SX = BKR + 16;                          // stride % 32 == 16 -> conflict-free b32 reads
+  constexpr int SY = (BNW % 32 == 16) ? BNW : BNW + 16;
+  constexpr int PX = KPW;                               // x pieces per thread
+  constexpr int PY = (NTW * 64 + 255) / 256;            // dy pieces per thread
+  constexpr int K4 = BKR / 4;                           // 16-byte pieces per pixel row of the x tile
+  constexpr int N4 = BNW / 4;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BP * (SX + SY)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tiles = p.kblocks * p.nblocks;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int kb = bid / p.nblocks, nb = bid - kb * p.nblocks;
+  const int k0 = kb * BKR, n0 = nb * BNW;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int hw = p.hout * p.wout;
+
+  // x pieces: fixed (tap, channel) per thread for the whole kernel, pixel varies per step.
+  const int xk4 = tid % K4, xp0 = tid / K4;  // pixel rows xp0 + (256/K4)*j
+  const int kglob = k0 + xk4 * 4;
+  const int tap = kglob / p.cin_p, xc = kglob - tap * p.cin_p;
+  const int xkh = tap / p.kw, xkw = tap - xkh * p.kw;
+  const bool xtap_ok = tap < p.kh * p.kw;
+  const int xdoff = ((xkh - p.pad_h) * p.win + (xkw - p.pad_w)) * p.cin_p + xc;
+
+  f32x4 rx[PX], ry[PY];
+  auto load_tile = [&](int step) {
+    const int mbase = m_begin + step * BP;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      const int m = mbase + xp0 + (256 / K4) * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xtap_ok && m < m_end) {
+        const int b = m / hw, r = m - b * hw;
+        const int ho = r / p.wout, wo = r - ho * p.wout;
+        const int hi = ho - p.pad_h + xkh, wi = wo - p.pad_w + xkw;
+        if ((unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win)
+          v = *reinterpret_cast<const f32x4*>(p.x + ((long)(b * p.hin + ho) * p.win + wo) * p.cin_p + xdoff);
+      }
+      rx[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < PY; ++j) {
+      const int e = tid + 256 * j;
+      const int pp = e / N4, n4 = e - pp * N4;
+      const int m = mbase + pp, n = n0 + n4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < BP * N4 && m < m_end && n < p.cout_p)
+        v = *reinterpret_cast<const f32x4*>(p.dy + (long)m * p.cout_p + n);
+      ry[j] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Xs = smem + buf * BP * (SX + SY);
+    float* Ys = Xs + BP * SX;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      const int pp = xp0 + (256 / K4) * j;
+      *reinterpret_cast<f32x4*>(Xs + pp * SX + xk4 * 4) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PY; ++j) {
+      const int e = tid + 256 * j;
+      const int pp = e / N4, n4 = e - pp * N4;
+      if (e < BP * N4) *reinterpret_cast<f32x4*>(Ys + pp * SY + n4 * 4) = ry[j];
+    }
+  };
+
+  f32x4 acc[KPW][NTW];
+#pragma unroll
+  for (int a = 0; a < KPW; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fi = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const float* Xs = smem + buf * BP * (SX + SY);
+    const float* Ys = Xs + BP * SX;
+#pragma unroll
+    for (int s = 0; s < BP / 4; ++s) {
+      float bx[KPW];
+#pragma unroll
+      for (int kt = 0; kt < KPW; ++kt) bx[kt] = Xs[(4 * s + fq) * SX + (wave * KPW + kt) * 16 + fi];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const float ay = Ys[(4 * s + fq) * SY + nt * 16 + fi];
+#pragma unroll
+        for (int kt = 0; kt < KPW; ++kt)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bx[kt], acc[kt][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  const int steps = (m_end - m_begin + BP - 1) / BP;
+  if (steps > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    const bool more = t + 1 < steps;
+    if (more) load_tile(t + 1);
+    compute(t & 1);
+    if (more) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  float* ws = p.ws + (long)split * p.n_pad16 * p.k_pad;
+#pragma unroll
+  for (int kt = 0; kt < KPW; ++kt) {
+    const int k = k0 + (wave * KPW + kt) * 16 + fi;
+    if (k < p.k_pad) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + nt * 16 + fq * 4 + r;
+          if (n < p.n_pad16) ws[(long)n * p.k_pad + k] = acc[kt][nt][r];
+        }
+      }
+    }
+  }
+}
+
+// out[i] = sum_s ws[s*stride + i], fixed order (deterministic).  n4 = element count / 4.
+__global__ void __launch_bounds__(256) slab_reduce_k(const float* __restrict__ ws, float* __restrict__ out,
+                                                     long n4, long stride4, int splits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* w = reinterpret_cast<const f32x4*>(ws);
+  f32x4 s = w[i];
+  for (int k = 1; k < splits; ++k) s += w[(long)k * stride4 + i];
+  reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+// Partial column sums of dy for the bias gradient: part[chunk][n] = sum_{m in chunk} dy[m][n].
+// Block = 4 row-lanes x 64 column groups of 4 channels.
+__global__ void __launch_bounds__(256) colsum_partial_k(const float* __restrict__ dy, float* __restrict__ part,
+                                                        int M, int cout_p, int n_pad16, int rows_per_chunk) {
+  __shared__ __attribute__((aligned(16))) float red[4][64 * 4];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int chunk = blockIdx.x;
+  const int m_begin = chunk * rows_per_chunk;
+  const int m_end = min(M, m_begin + rows_per_chunk);
+  const int ng = cout_p >> 2;
+  for (int g0 = 0; g0 < (n_pad16 >> 2); g0 += 64) {
+    const int g = g0 + cx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (g < ng)
+      for (int m = m_begin + ry; m < m_end; m += 4) s += *reinterpret_cast<const f32x4*>(dy + (long)m * cout_p + g * 4);
+    *reinterpret_cast<f32x4*>(&red[ry][cx * 4]) = s;
+    __syncthreads();
+    if (ry == 0 && g < (n_pad16 >> 2)) {
+      f32x4 t = *reinterpret_cast<f32x4*>(&red[0][cx * 4]);
+      t += *reinterpret_cast<f32x4*>(&red[1][cx * 4]);
+      t += *reinterpret_cast<f32x4*>(&red[2][cx * 4]);
+      t += *reinterpret_cast<f32x4*>(&red[3][cx * 4]);
+      *reinterpret_cast<f32x4*>(part + (long)chunk * n_pad16 + g * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight layout transforms (one thread per packed element).
+// ------------------------------------------------------------------------------------------
+__global__ void pack_w_k(const float* __restrict__ w_oihw, float* __restrict__ wp, efm_conv_desc d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)d.n_pad16 * d.k_pad;
+  if (i >= total) return;
+  const int n = (int)(i / d.k_pad), k = (int)(i - (long)n * d.k_pad);
+  const int tap = k / d.cin_p, ci = k - tap * d.cin_p;
+  float v = 0.f;
+  if (n < d.cout && tap < d.kh * d.kw && ci < d.cin) {
+    const int kh = tap / d.kw, kw = tap - kh * d.kw;
+    v = w_oihw[(((long)n * d.cin + ci) * d.kh + kh) * d.kw + kw];
+  }
+  wp[i] = v;
+}
+
+__global__ void unpack_w_k(const float* __restrict__ wp, float* __restrict__ w_oihw, efm_conv_desc d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)d.cout * d.cin * d.kh * d.kw;
+  if (i >= total) return;
+  long r = i;
+  const int kw = (int)(r % d.kw); r /= d.kw;
+  const int kh = (int)(r % d.kh); r /= d.kh;
+  const int ci = (int)(r % d.cin); r /= d.cin;
+  const int n = (int)r;
+  w_oihw[i] = wp[(long)n * d.k_pad + (kh * d.kw + kw) * d.cin_p + ci];
+}
+
+// wd[ci][(KH-1-kh, KW-1-kw, co)] = w[co][(kh, kw, ci)]
+__global__ void dgrad_w_k(const float* __restrict__ wp, float* __restrict__ wd, efm_conv_desc d) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)d.dn_pad16 * d.dk_pad;
+  if (i >= total) return;
+  const int ci = (int)(i / d.dk_pad), k = (int)(i - (long)ci * d.dk_pad);
+  const int tap = k / d.cout_p, co = k - tap * d.cout_p;
+  float v = 0.f;
+  if (ci < d.cin && tap < d.kh * d.kw && co < d.cout) {
+    const int fkh = tap / d.kw, fkw = tap - fkh * d.kw;
+    const int kh = d.kh - 1 - fkh, kw = d.kw - 1 - fkw;
+    v = wp[(long)co * d.k_pad + (kh * d.kw + kw) * d.cin_p + ci];
+  }
+  wd[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-side dispatch
+// ------------------------------------------------------------------------------------------
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <int MT>
+int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
+  switch (NT) {
+#define EFM_CASE(N)                                          \
+  case N:                                                    \
+    hipLaunchKernelGGL((conv_fwd_k<MT, N>), grid, dim3(256), 0, s, p); \
+    return EFM_OK;
+    EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
+#undef EFM_CASE
+  }
+  efm::set_error("conv_fwd: unsupported NT=%d", NT);
+  return EFM_E_INVALID;
+}
+
+int round_nt(int nt) {
+  static const int ok[] = {3, 5, 6, 7, 8, 9, 11, 13};
+  for (int v : ok)
+    if (v >= nt) return v;
+  return 13;
+}
+
+// Generic forward-type launch: y[m][n] = sum_k A(x)[m][k] w[n][k] + bias[n] + res[m][n]
+int run_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int batch,
+            int hin, int win, int cin_p, int hout, int wout, int cout_p, int kh, int kw, int pad_h,
+            int pad_w, int n_pad16, int k_pad, hipStream_t s) {
+  ConvP p;
+  p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
+  p.M = batch * hout * wout;
+  p.hin = hin; p.win = win; p.cin_p = cin_p;
+  p.hout = hout; p.wout = wout; p.cout_p = cout_p;
+  p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
+  p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
+  const int tiles = n_pad16 / 16;
+  const int nblocks = (tiles + 12) / 13;
+  const int NT = round_nt((tiles + nblocks - 1) / nblocks);
+  p.nblocks = (tiles + NT - 1) / NT;
+  int MT = 2;
+  // keep at least ~4 blocks per CU in flight; small problems use the 64-row tile
+  if ((long)efm::cdiv(p.M, 128) * p.nblocks < 1024) MT = 1;
+  MT = env_int("EFM_CONV_MT", MT);
+  const int BM = 64 * MT;
+  const long mblocks = efm::cdiv(p.M, BM);
+  dim3 grid((unsigned)(mblocks * p.nblocks));
+  int rc = (MT == 2) ? launch_fwd_nt<2>(NT, grid, s, p) : launch_fwd_nt<1>(NT, grid, s, p);
+  if (rc != EFM_OK) return rc;
+  return efm::check_launch("conv_fwd");
+}
+
+template <int KPW>
+int launch_wgrad_nt(int NTW, dim3 grid, hipStream_t s, const WgradP& p) {
+  switch (NTW) {
+#define EFM_CASE(N)                                             \
+  case N:                                                       \
+    hipLaunchKernelGGL((conv_wgrad_k<KPW, N>), grid, dim3(256), 0, s, p); \
+    return EFM_OK;
+    EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
+#undef EFM_CASE
+  }
+  efm::set_error("conv_wgrad: unsupported NTW=%d", NTW);
+  return EFM_E_INVALID;
+}
+
+struct WgradPlan {
+  int KPW, NTW, kblocks, nblocks, splits, m_per_split, chunks, rows_per_chunk;
+  size_t ws_floats;  // wgrad slabs + bias partials
+};
+
+WgradPlan plan_wgrad(const efm_conv_desc* d) {
+  WgradPlan pl;
+  const int M = d->batch * d->hout * d->wout;
+  const int ktiles = d->k_pad / 16, ntiles = d->n_pad16 / 16;
+  pl.KPW = env_int("EFM_WGRAD_KPW", (ktiles >= 32) ? 2 : 1);
+  if (pl.KPW != 2) pl.KPW = 1;
+  pl.kblocks = (ktiles + 4 * pl.KPW - 1) / (4 * pl.KPW);
+  const int nb = (ntiles + 12) / 13;
+  pl.NTW = round_nt((ntiles + nb - 1) / nb);
+  pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
+  const int base = pl.kblocks * pl.nblocks;
+  const int target = env_int("EFM_WGRAD_BLOCKS", 2048);
+  int splits = (target + base - 1) / base;
+  const int max_splits = (M + 255) / 256;  // at least 256 pixels (16 steps) per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int mps = (M + splits - 1) / splits;
+  mps = (mps + 15) & ~15;
+  pl.m_per_split = mps;
+  pl.splits = (M + mps - 1) / mps;
+  pl.rows_per_chunk = 2048;
+  pl.chunks = (M + pl.rows_per_chunk - 1) / pl.rows_per_chunk;
+  pl.ws_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad + (size_t)pl.chunks * d->n_pad16;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, int cout, int kh, int kw,
+                       int pad_h, int pad_w) {
+  EFM_REQUIRE(d != nullptr, "conv_desc_init: null descriptor");
+  EFM_REQUIRE(batch > 0 && hin > 0 && win > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && pad_h >= 0 && pad_w >= 0,
+              "conv_desc_init: non-positive dimension");
+  d->batch = batch;
+  d->hin = hin; d->win = win; d->cin = cin; d->cin_p = efm_pad4(cin);
+  d->kh = kh; d->kw = kw; d->pad_h = pad_h; d->pad_w = pad_w;
+  d->hout = hin + 2 * pad_h - kh + 1;
+  d->wout = win + 2 * pad_w - kw + 1;
+  EFM_REQUIRE(d->hout > 0 && d->wout > 0, "conv_desc_init: kernel larger than padded input");
+  d->cout = cout; d->cout_p = efm_pad4(cout);
+  d->n_pad16 = efm_pad16(cout);
+  d->k_pad = efm_pad16(kh * kw * d->cin_p);
+  d->dn_pad16 = efm_pad16(cin);
+  d->dk_pad = efm_pad16(kh * kw * d->cout_p);
+  EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 31) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 31),
+              "conv_desc_init: tensor exceeds 2^31 elements");
+  return EFM_OK;
+}
+
+size_t efm_conv_weight_elems(const efm_conv_desc* d) { return (size_t)d->n_pad16 * d->k_pad; }
+size_t efm_conv_dgrad_weight_elems(const efm_conv_desc* d) { return (size_t)d->dn_pad16 * d->dk_pad; }
+size_t efm_conv_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wgrad(d).ws_floats * sizeof(float); }
+
+int efm_conv_pack_weights(const efm_conv_desc* d, const float* w_oihw, float* w_packed, void* stream) {
+  EFM_REQUIRE(d && w_oihw && w_packed, "conv_pack_weights: null argument");
+  const long total = (long)d->n_pad16 * d->k_pad;
+  hipLaunchKernelGGL(pack_w_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, w_packed, *d);
+  return efm::check_launch("conv_pack_weights");
+}
+
+int efm_conv_unpack_weights(const efm_conv_desc* d, const float* w_packed, float* w_oihw, void* stream) {
+  EFM_REQUIRE(d && w_oihw && w_packed, "conv_unpack_weights: null argument");
+  const long total = (long)d->cout * d->cin * d->kh * d->kw;
+  hipLaunchKernelGGL(unpack_w_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, w_oihw, *d);
+  return efm::check_launch("conv_unpack_weights");
+}
+
+int efm_conv_make_dgrad_weights(const efm_conv_desc* d, const float* w_packed, float* wd_packed, void* stream) {
+  EFM_REQUIRE(d && wd_packed && w_packed, "conv_make_dgrad_weights: null argument");
+  const long total = (long)d->dn_pad16 * d->dk_pad;
+  hipLaunchKernelGGL(dgrad_w_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, wd_packed, *d);
+  return efm::check_launch("conv_make_dgrad_weights");
+}
+
+int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
+                 const float* residual, float* y, void* stream) {
+  EFM_REQUIRE(d && x && w_packed && y, "conv_fwd: null argument");
+  return run_fwd(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
+                 d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, (hipStream_t)stream);
+}
+
+int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed, const float* add,
+                      float* dx, void* stream) {
+  EFM_REQUIRE(d && dy && wd_packed && dx, "conv_bwd_data: null argument");
+  // full correlation of dy with the flipped kernel: pad' = k - 1 - pad
+  return run_fwd(dy, wd_packed, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->hin, d->win, d->cin_p,
+                 d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, (hipStream_t)stream);
+}
+
+int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && dy && dw_packed, "conv_bwd_weight: null argument");
+  const WgradPlan pl = plan_wgrad(d);
+  if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
+    efm::set_error("conv_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
+    return EFM_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  WgradP p;
+  p.x = x; p.dy = dy; p.ws = (float*)workspace;
+  p.M = d->batch * d->hout * d->wout;
+  p.hin = d->hin; p.win = d->win; p.cin_p = d->cin_p;
+  p.hout = d->hout; p.wout = d->wout; p.cout_p = d->cout_p;
+  p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad;
+  p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
+  dim3 grid((unsigned)(pl.kblocks * pl.nblocks * pl.splits));
+  int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
+  if (rc != EFM_OK) return rc;
+  rc = efm::check_launch("conv_wgrad");
+  if (rc != EFM_OK) return rc;
+  const long n4 = (long)d->n_pad16 * d->k_pad / 4;
+  hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(n4, 256)), dim3(256), 0, s, (const float*)workspace,
+                     dw_packed, n4, n4, pl.splits);
+  rc = efm::check_launch("conv_wgrad_reduce");
+  if (rc != EFM_OK) return rc;
+  if (dbias) {
+    float* part = (float*)workspace + (size_t)pl.splits * d->n_pad16 * d->k_pad;
+    hipLaunchKernelGGL(colsum_partial_k, dim3(pl.chunks), dim3(256), 0, s, dy, part, p.M, d->cout_p, d->n_pad16,
+                       pl.rows_per_chunk);
+    rc = efm::check_launch("conv_bias_colsum");
+    if (rc != EFM_OK) return rc;
+    const long b4 = d->n_pad16 / 4;
+    hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(b4, 256)), dim3(256), 0, s, (const float*)part, dbias,
+                       b4, b4, pl.chunks);
+    rc = efm::check_launch("conv_bias_reduce");
+  }
+  return rc;
+}
+
+}  // extern "C"

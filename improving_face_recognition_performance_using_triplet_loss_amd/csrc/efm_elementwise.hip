@@ -1,0 +1,264 @@
+// HBM-bound NHWC kernels around the convolutions: layout conversion at the boundary, MFM
+// (max / min feature map), 2x2 max pooling.  All tensors fp32, channel stride padded to 4,
+// pad channels kept zero.
+//
+// Replaces SliceChannel/maximum/minimum/Concat (ref: efm_symbol.py:25-30,34-39,55-60,63-64,
+// 69-77,96-101; lightcnn.py:22-27,32-37,53-66,123-128) and Pooling (ref: efm_symbol.py:78;
+// lightcnn.py:83,89,95,101,107), which MXNet runs as 6+ separate elementwise kernels per MFM.
+#include "efm_common.h"
+
+namespace {
+
+// ---- NCHW <-> NHWC(pad4) -------------------------------------------------------------------
+// one thread per output pixel-channel-group of 4: reads 4 strided planes, writes 16 B.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_k(const float* __restrict__ x, float* __restrict__ y,
+                                                      long pixels, int c, int hw, int cp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ng = cp >> 2;
+  if (i >= pixels * ng) return;
+  const long pix = i / ng;
+  const int g = (int)(i - pix * ng);
+  const long b = pix / hw, r = pix - b * hw;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ch = g * 4 + k;
+    if (ch < c) v[k] = x[(b * c + ch) * hw + r];
+  }
+  *reinterpret_cast<f32x4*>(y + pix * cp + g * 4) = v;
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_k(const float* __restrict__ x, float* __restrict__ y,
+                                                      long total, int c, int hw, int cp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long r = i % hw;
+  const long t = i / hw;
+  const int ch = (int)(t % c);
+  const long b = t / c;
+  y[i] = x[(b * hw + r) * cp + ch];
+}
+
+// ---- MFM -----------------------------------------------------------------------------------
+// thread = (row, j) with j < cw = c/ways + (pad channels of y); consecutive threads walk j so
+// each of the `ways` slice reads and both writes are coalesced runs.
+template <int WAYS>
+__global__ void __launch_bounds__(256) mfm_fwd_k(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                 int c, int cp_in, int cp_out, int cw) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cw) return;
+  const long row = i / cw;
+  const int j = (int)(i - row * cw);
+  const int cs = c / WAYS;
+  const float* xr = x + row * cp_in;
+  float* yr = y + row * cp_out;
+  if (j < cs) {
+    if (WAYS == 3) {
+      const float s0 = xr[j], s1 = xr[cs + j], s2 = xr[2 * cs + j];
+      yr[j] = fmaxf(fmaxf(s0, s1), s2);
+      yr[cs + j] = fminf(fminf(s0, s1), s2);
+    } else {
+      yr[j] = fmaxf(xr[j], xr[cs + j]);
+    }
+  } else {
+    const int cout = (WAYS == 3) ? 2 * cs : cs;
+    const int pc = cout + (j - cs);
+    if (pc < cp_out) yr[pc] = 0.f;
+  }
+}
+
+// MXNet: d maximum(l,r) -> l if l >= r else r ; d minimum(l,r) -> l if l <= r else r.
+// ORDER_GROUP: max(max(s0,s1),s2); ORDER_RES: max(s2, max(s0,s1)).
+template <int WAYS>
+__global__ void __launch_bounds__(256) mfm_bwd_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                 const float* __restrict__ add, float* __restrict__ dx, long rows,
+                                                 int c, int cp_in, int cp_out, int cw, int order) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cw) return;
+  const long row = i / cw;
+  const int j = (int)(i - row * cw);
+  const int cs = c / WAYS;
+  const float* xr = x + row * cp_in;
+  const float* gr = dy + row * cp_out;
+  float* dr = dx + row * cp_in;
+  const float* ar = add ? add + row * cp_in : nullptr;
+  if (j < cs) {
+    if (WAYS == 3) {
+      const float s0 = xr[j], s1 = xr[cs + j], s2 = xr[2 * cs + j];
+      const float gmax = gr[j], gmin = gr[cs + j];
+      int imax = (s0 >= s1) ? 0 : 1;
+      int imin = (s0 <= s1) ? 0 : 1;
+      const float m1 = fmaxf(s0, s1), n1 = fminf(s0, s1);
+      if (order == EFM_MFM_ORDER_GROUP) {
+        if (!(m1 >= s2)) imax = 2;
+        if (!(n1 <= s2)) imin = 2;
+      } else {
+        if (s2 >= m1) imax = 2;
+        if (s2 <= n1) imin = 2;
+      }
+      float d0 = (imax == 0 ? gmax : 0.f) + (imin == 0 ? gmin : 0.f);
+      float d1 = (imax == 1 ? gmax : 0.f) + (imin == 1 ? gmin : 0.f);
+      float d2 = (imax == 2 ? gmax : 0.f) + (imin == 2 ? gmin : 0.f);
+      if (ar) { d0 += ar[j]; d1 += ar[cs + j]; d2 += ar[2 * cs + j]; }
+      dr[j] = d0; dr[cs + j] = d1; dr[2 * cs + j] = d2;
+    } else {
+      const float s0 = xr[j], s1 = xr[cs + j];
+      const float g = gr[j];
+      float d0 = (s0 >= s1) ? g : 0.f, d1 = (s0 >= s1) ? 0.f : g;
+      if (ar) { d0 += ar[j]; d1 += ar[cs + j]; }
+      dr[j] = d0; dr[cs + j] = d1;
+    }
+  } else {
+    const int pc = WAYS * cs + (j - cs);  // pad channels of x (c % WAYS == 0 => c == WAYS*cs)
+    if (pc < cp_in) dr[pc] = 0.f;
+  }
+}
+
+// ---- 2x2 / stride 2 max pooling, floor ------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool2_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                      long total, int h, int w, int ho, int wo, int ng) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i % ng);
+  long t = i / ng;
+  const int ow = (int)(t % wo); t /= wo;
+  const int oh = (int)(t % ho);
+  const long b = t / ho;
+  const int cp = ng * 4;
+  const float* p00 = x + ((b * h + 2 * oh) * w + 2 * ow) * cp + g * 4;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p00);
+  const f32x4 bq = *reinterpret_cast<const f32x4*>(p00 + cp);
+  const f32x4 cq = *reinterpret_cast<const f32x4*>(p00 + (long)w * cp);
+  const f32x4 dq = *reinterpret_cast<const f32x4*>(p00 + (long)w * cp + cp);
+  f32x4 m;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], bq[k]), fmaxf(cq[k], dq[k]));
+  *reinterpret_cast<f32x4*>(y + i * 4) = m;
+}
+
+// Gradient to the first maximum of the window in scan order (h, then w), as MXNet's pooling
+// backward does; every window position is written (dx needs no memset when h, w are even; odd
+// trailing rows/columns are zeroed by the threads of the last window row/column).
+__global__ void __launch_bounds__(256) maxpool2_bwd_k(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, long total, int h, int w, int ho,
+                                                      int wo, int ng) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i % ng);
+  long t = i / ng;
+  const int ow = (int)(t % wo); t /= wo;
+  const int oh = (int)(t % ho);
+  const long b = t / ho;
+  const int cp = ng * 4;
+  const long o00 = ((b * h + 2 * oh) * w + 2 * ow) * cp + g * 4;
+  const long o01 = o00 + cp, o10 = o00 + (long)w * cp, o11 = o10 + cp;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(x + o00);
+  const f32x4 bq = *reinterpret_cast<const f32x4*>(x + o01);
+  const f32x4 cq = *reinterpret_cast<const f32x4*>(x + o10);
+  const f32x4 dq = *reinterpret_cast<const f32x4*>(x + o11);
+  const f32x4 gq = *reinterpret_cast<const f32x4*>(dy + i * 4);
+  f32x4 ra, rb, rc, rd;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int idx = 0;
+    float m = a[k];
+    if (bq[k] > m) { m = bq[k]; idx = 1; }
+    if (cq[k] > m) { m = cq[k]; idx = 2; }
+    if (dq[k] > m) { m = dq[k]; idx = 3; }
+    ra[k] = idx == 0 ? gq[k] : 0.f;
+    rb[k] = idx == 1 ? gq[k] : 0.f;
+    rc[k] = idx == 2 ? gq[k] : 0.f;
+    rd[k] = idx == 3 ? gq[k] : 0.f;
+  }
+  *reinterpret_cast<f32x4*>(dx + o00) = ra;
+  *reinterpret_cast<f32x4*>(dx + o01) = rb;
+  *reinterpret_cast<f32x4*>(dx + o10) = rc;
+  *reinterpret_cast<f32x4*>(dx + o11) = rd;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const bool last_w = (ow == wo - 1) && (w & 1), last_h = (oh == ho - 1) && (h & 1);
+  if (last_w) {
+    *reinterpret_cast<f32x4*>(dx + o01 + cp) = z;
+    *reinterpret_cast<f32x4*>(dx + o11 + cp) = z;
+  }
+  if (last_h) {
+    *reinterpret_cast<f32x4*>(dx + o10 + (long)w * cp) = z;
+    *reinterpret_cast<f32x4*>(dx + o11 + (long)w * cp) = z;
+    if (last_w) *reinterpret_cast<f32x4*>(dx + o11 + (long)w * cp + cp) = z;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int efm_nchw_to_nhwc(const float* x, float* y, int batch, int c, int h, int w, void* stream) {
+  EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad argument");
+  const int cp = efm_pad4(c);
+  const long pixels = (long)batch * h * w;
+  const long n = pixels * (cp >> 2);
+  hipLaunchKernelGGL(nchw_to_nhwc_k, dim3((unsigned)efm::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     pixels, c, h * w, cp);
+  return efm::check_launch("nchw_to_nhwc");
+}
+
+int efm_nhwc_to_nchw(const float* x, float* y, int batch, int c, int h, int w, void* stream) {
+  EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0, "nhwc_to_nchw: bad argument");
+  const long total = (long)batch * c * h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     total, c, h * w, efm_pad4(c));
+  return efm::check_launch("nhwc_to_nchw");
+}
+
+int efm_mfm_fwd(const float* x, float* y, int64_t rows, int c, int ways, void* stream) {
+  EFM_REQUIRE(x && y && rows > 0 && c > 0, "mfm_fwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfm_fwd: c=%d not divisible by ways=%d", c, ways);
+  const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
+  const int cp_in = efm_pad4(c), cp_out = efm_pad4(cout);
+  const int cw = cs + (cp_out - cout);
+  const long n = rows * cw;
+  dim3 grid((unsigned)efm::cdiv(n, 256));
+  if (ways == 3)
+    hipLaunchKernelGGL(mfm_fwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, c, cp_in, cp_out, cw);
+  else
+    hipLaunchKernelGGL(mfm_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, c, cp_in, cp_out, cw);
+  return efm::check_launch("mfm_fwd");
+}
+
+int efm_mfm_bwd(const float* x, const float* dy, const float* add, float* dx, int64_t rows, int c, int ways,
+                int order, void* stream) {
+  EFM_REQUIRE(x && dy && dx && rows > 0 && c > 0, "mfm_bwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfm_bwd: c=%d not divisible by ways=%d", c, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "mfm_bwd: bad order %d", order);
+  const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
+  const int cp_in = efm_pad4(c), cp_out = efm_pad4(cout);
+  const int cw = cs + (cp_in - c);
+  const long n = rows * cw;
+  dim3 grid((unsigned)efm::cdiv(n, 256));
+  if (ways == 3)
+    hipLaunchKernelGGL(mfm_bwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (long)rows, c, cp_in,
+                       cp_out, cw, order);
+  else
+    hipLaunchKernelGGL(mfm_bwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (long)rows, c, cp_in,
+                       cp_out, cw, order);
+  return efm::check_launch("mfm_bwd");
+}
+
+int efm_maxpool2_fwd(const float* x, float* y, int batch, int h, int w, int c, void* stream) {
+  EFM_REQUIRE(x && y && batch > 0 && h >= 2 && w >= 2 && c > 0, "maxpool2_fwd: bad argument");
+  const int ho = h / 2, wo = w / 2, ng = efm_pad4(c) >> 2;
+  const long total = (long)batch * ho * wo * ng;
+  hipLaunchKernelGGL(maxpool2_fwd_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     total, h, w, ho, wo, ng);
+  return efm::check_launch("maxpool2_fwd");
+}
+
+int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream) {
+  EFM_REQUIRE(x && dy && dx && batch > 0 && h >= 2 && w >= 2 && c > 0, "maxpool2_bwd: bad argument");
+  const int ho = h / 2, wo = w / 2, ng = efm_pad4(c) >> 2;
+  const long total = (long)batch * ho * wo * ng;
+  hipLaunchKernelGGL(maxpool2_bwd_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy,
+                     dx, total, h, w, ho, wo, ng);
+  return efm::check_launch("maxpool2_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+// Embedding-head kernels: L2 normalisation, negative gather, triplet-margin loss, cosine pairs,
+// batch-all-pairs cosine (Gram) matrix, semi-hard mining, and the flat-buffer optimisers.
+// One 64-lane wavefront per embedding row; reductions are xor-shuffle trees (no LDS, no atomics),
+// so every result is bitwise reproducible.
+//
+// Replaces: mx.nd.norm + divide (ref: train_efm.py:241; final_efm.py:240-243), the Python
+// negative-pick copy loop (ref: train_efm.py:234-239; pre-trained_efm_v3.py:202-207),
+// gluon.loss.TripletLoss (ref: train_efm.py:210,241; pre-trained_efm_v3.py:183,210), cosine_dist
+// (ref: train_efm.py:26-34), Trainer.step with sgd / adam (ref: train_efm.py:213-214,245;
+// pre-trained_efm_v3.py:185,212; mutli_gpu_v3.py:159).
+#include "efm_common.h"
+
+namespace {
+
+using efm::wave_sum;
+
+// ---- L2 normalisation ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) l2norm_row_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                        float* __restrict__ norm, int rows, int d, int ldx, int ldy) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s = fmaf(xr[k], xr[k], s);
+  s = wave_sum(s);
+  const float nrm = sqrtf(s);
+  if (lane == 0) norm[row] = nrm;
+  float* yr = y + (long)row * ldy;
+  for (int k = lane; k < d; k += 64) yr[k] = xr[k] / nrm;
+}
+
+// dx = (dy - y * <y, dy>) / ||x||
+__global__ void __launch_bounds__(256) l2norm_row_bwd_k(const float* __restrict__ y, const float* __restrict__ norm,
+                                                        const float* __restrict__ dy, float* __restrict__ dx, int rows,
+                                                        int d, int ldy, int lddy, int lddx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* yr = y + (long)row * ldy;
+  const float* gr = dy + (long)row * lddy;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s = fmaf(yr[k], gr[k], s);
+  s = wave_sum(s);
+  const float inv = 1.f / norm[row];
+  float* dr = dx + (long)row * lddx;
+  for (int k = lane; k < d; k += 64) dr[k] = (gr[k] - yr[k] * s) * inv;
+}
+
+// Whole-matrix reductions for the Frobenius mode: single block of 1024 threads (matrices here
+// are <= 16384 x 684), fixed summation order.
+__device__ float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  float t = (lane < 16) ? sh[lane] : 0.f;
+  t = wave_sum(t);
+  __syncthreads();
+  return t;
+}
+
+__global__ void __launch_bounds__(1024) l2norm_frob_fwd_k(const float* __restrict__ x, float* __restrict__ y,
+                                                          float* __restrict__ norm, int rows, int d, int ldx, int ldy) {
+  __shared__ float sh[16];
+  const long total = (long)rows * d;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const long r = i / d;
+    const float v = x[r * ldx + (i - r * d)];
+    s = fmaf(v, v, s);
+  }
+  const float nrm = sqrtf(block_sum_1024(s, sh));
+  if (threadIdx.x == 0) norm[0] = nrm;
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const long r = i / d;
+    const long c = i - r * d;
+    y[r * ldy + c] = x[r * ldx + c] / nrm;
+  }
+}
+
+__global__ void __launch_bounds__(1024) l2norm_frob_bwd_k(const float* __restrict__ y, const float* __restrict__ norm,
+                                                          const float* __restrict__ dy, float* __restrict__ dx, int rows,
+                                                          int d, int ldy, int lddy, int lddx) {
+  __shared__ float sh[16];
+  const long total = (long)rows * d;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const long r = i / d;
+    const long c = i - r * d;
+    s = fmaf(y[r * ldy + c], dy[r * lddy + c], s);
+  }
+  s = block_sum_1024(s, sh);
+  const float inv = 1.f / norm[0];
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const long r = i / d;
+    const long c = i - r * d;
+    dx[r * lddx + c] = (dy[r * lddy + c] - y[r * ldy + c] * s) * inv;
+  }
+}
+
+// ---- row gather --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_rows_k(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                     float* __restrict__ y, int rows, int d, int ldx, int ldy) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long)idx[row] * ldx;
+  float* yr = y + (long)row * ldy;
+  for (int k = lane; k < d; k += 64) yr[k] = xr[k];
+}
+
+// ---- triplet loss ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) triplet_fwd_k(const float* __restrict__ a, const float* __restrict__ p,
+                                                     const float* __restrict__ n, float* __restrict__ loss, int rows,
+                                                     int d, int lda, int ldp, int ldn, float margin) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* ar = a + (long)row * lda;
+  const float* pr = p + (long)row * ldp;
+  const float* nr = n + (long)row * ldn;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float dp = pr[k] - ar[k], dn = nr[k] - ar[k];
+    s += dp * dp - dn * dn;
+  }
+  s = wave_sum(s);
+  if (lane == 0) loss[row] = fmaxf(s + margin, 0.f);
+}
+
+// d loss_i / d a = 2 (n - p), / d p = 2 (p - a), / d n = -2 (n - a), gated by loss_i > 0.
+__global__ void __launch_bounds__(256) triplet_bwd_k(const float* __restrict__ a, const float* __restrict__ p,
+                                                     const float* __restrict__ n, const float* __restrict__ loss,
+                                                     const float* __restrict__ gloss, float* __restrict__ da,
+                                                     float* __restrict__ dp, float* __restrict__ dn, int rows, int d,
+                                                     int lda, int ldp, int ldn, int ldg) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float g = (loss[row] > 0.f) ? 2.f * gloss[row] : 0.f;
+  const float* ar = a + (long)row * lda;
+  const float* pr = p + (long)row * ldp;
+  const float* nr = n + (long)row * ldn;
+  for (int k = lane; k < d; k += 64) {
+    const float av = ar[k], pv = pr[k], nv = nr[k];
+    if (da) da[(long)row * ldg + k] = g * (nv - pv);
+    if (dp) dp[(long)row * ldg + k] = g * (pv - av);
+    if (dn) dn[(long)row * ldg + k] = -g * (nv - av);
+  }
+}
+
+// ---- cosine similarities -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cosine_pairs_k(const float* __restrict__ a, const float* __restrict__ p,
+                                                      const float* __restrict__ n, float* __restrict__ s_ap,
+                                                      float* __restrict__ s_an, int rows, int d, int lda, int ldp,
+                                                      int ldn) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* ar = a + (long)row * lda;
+  const float* pr = p + (long)row * ldp;
+  const float* nr = n + (long)row * ldn;
+  float aa = 0.f, pp = 0.f, nn = 0.f, ap = 0.f, an = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float av = ar[k], pv = pr[k], nv = nr[k];
+    aa = fmaf(av, av, aa); pp = fmaf(pv, pv, pp); nn = fmaf(nv, nv, nn);
+    ap = fmaf(av, pv, ap); an = fmaf(av, nv, an);
+  }
+  aa = wave_sum(aa); pp = wave_sum(pp); nn = wave_sum(nn); ap = wave_sum(ap); an = wave_sum(an);
+  if (lane == 0) {
+    const float na = sqrtf(aa);
+    s_ap[row] = ap / (na * sqrtf(pp));
+    s_an[row] = an / (na * sqrtf(nn));
+  }
+}
+
+// g[i][j] = <e_i, e_j> / (|e_i||e_j|).  Block = row i (4 waves), e_i staged in LDS; each wave walks
+// columns j = wave, wave+4, ...; a lane-strided dot + shuffle reduction per pair.
+__global__ void __launch_bounds__(256) gram_cosine_k(const float* __restrict__ e, float* __restrict__ g, int rows,
+                                                     int d, int lde) {
+  extern __shared__ __attribute__((aligned(16))) float ei[];
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < d; k += 256) ei[k] = e[(long)i * lde + k];
+  __syncthreads();
+  float ii = 0.f;
+  for (int k = lane; k < d; k += 64) ii = fmaf(ei[k], ei[k], ii);
+  ii = wave_sum(ii);
+  for (int j = wv; j < rows; j += 4) {
+    const float* ej = e + (long)j * lde;
+    float dot = 0.f, jj = 0.f;
+    for (int k = lane; k < d; k += 64) {
+      const float v = ej[k];
+      dot = fmaf(ei[k], v, dot);
+      jj = fmaf(v, v, jj);
+    }
+    dot = wave_sum(dot);
+    jj = wave_sum(jj);
+    if (lane == 0) g[(long)i * rows + j] = dot / (sqrtf(ii) * sqrtf(jj));
+  }
+}
+
+// Semi-hard negative per anchor: one wave per anchor; lanes scan candidates j, keep
+// (best semi-hard: smallest d_an above d_ap) and (fallback: largest d_an); lowest index wins ties.
+__global__ void __launch_bounds__(256) mine_semihard_k(const float* __restrict__ g, const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ anchor_idx,
+                                                       const int32_t* __restrict__ pos_idx, int32_t* __restrict__ neg_idx,
+                                                       int n_anchor, int rows) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_anchor) return;
+  const int a = anchor_idx[t], p = pos_idx[t];
+  const int la = labels[a];
+  const float* ga = g + (long)a * rows;
+  const float d_ap = 1.f - ga[p];
+  float best_sh = INFINITY, best_fb = -INFINITY;
+  int i_sh = 0x7fffffff, i_fb = 0x7fffffff;
+  for (int j = lane; j < rows; j += 64) {
+    if (labels[j] == la) continue;
+    const float dj = 1.f - ga[j];
+    if (dj > d_ap && dj < best_sh) { best_sh = dj; i_sh = j; }
+    if (dj > best_fb) { best_fb = dj; i_fb = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float os = __shfl_xor(best_sh, o, 64), of = __shfl_xor(best_fb, o, 64);
+    const int ois = __shfl_xor(i_sh, o, 64), oif = __shfl_xor(i_fb, o, 64);
+    if (os < best_sh || (os == best_sh && ois < i_sh)) { best_sh = os; i_sh = ois; }
+    if (of > best_fb || (of == best_fb && oif < i_fb)) { best_fb = of; i_fb = oif; }
+  }
+  if (lane == 0) neg_idx[t] = (i_sh != 0x7fffffff) ? i_sh : ((i_fb != 0x7fffffff) ? i_fb : -1);
+}
+
+// ---- optimisers --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sgd_k(float* __restrict__ w, const float* __restrict__ g, long n4, float lr,
+                                             float wd, float rescale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+  const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wv[k] = wv[k] - lr * (rescale * gv[k] + wd * wv[k]);
+  reinterpret_cast<f32x4*>(w)[i] = wv;
+}
+
+__global__ void __launch_bounds__(256) adam_k(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long n4, float lr_t, float beta1, float beta2,
+                                              float eps, float wd, float rescale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+  const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+  f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gr = rescale * gv[k] + wd * wv[k];
+    mv[k] = beta1 * mv[k] + (1.f - beta1) * gr;
+    vv[k] = beta2 * vv[k] + (1.f - beta2) * gr * gr;
+    wv[k] = wv[k] - lr_t * mv[k] / (sqrtf(vv[k]) + eps);
+  }
+  reinterpret_cast<f32x4*>(w)[i] = wv;
+  reinterpret_cast<f32x4*>(m)[i] = mv;
+  reinterpret_cast<f32x4*>(v)[i] = vv;
+}
+
+}  // namespace
+
+extern "C" {
+
+int efm_l2norm_fwd(const float* x, float* y, float* norm_out, int rows, int d, int ldx, int ldy, int mode, void* stream) {
+  EFM_REQUIRE(x && y && norm_out && rows > 0 && d > 0 && ldx >= d && ldy >= d, "l2norm_fwd: bad argument");
+  if (mode == EFM_L2_ROW)
+    hipLaunchKernelGGL(l2norm_row_fwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, norm_out, rows, d, ldx, ldy);
+  else if (mode == EFM_L2_FROBENIUS)
+    hipLaunchKernelGGL(l2norm_frob_fwd_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, norm_out, rows, d, ldx, ldy);
+  else
+    EFM_REQUIRE(false, "l2norm_fwd: bad mode %d", mode);
+  return efm::check_launch("l2norm_fwd");
+}
+
+int efm_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx, int rows, int d, int ldy, int lddy,
+                   int lddx, int mode, void* stream) {
+  EFM_REQUIRE(y && norm && dy && dx && rows > 0 && d > 0, "l2norm_bwd: bad argument");
+  if (mode == EFM_L2_ROW)
+    hipLaunchKernelGGL(l2norm_row_bwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, norm, dy, dx, rows, d, ldy, lddy, lddx);
+  else if (mode == EFM_L2_FROBENIUS)
+    hipLaunchKernelGGL(l2norm_frob_bwd_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, y, norm, dy, dx, rows, d, ldy, lddy, lddx);
+  else
+    EFM_REQUIRE(false, "l2norm_bwd: bad mode %d", mode);
+  return efm::check_launch("l2norm_bwd");
+}
+
+int efm_gather_rows(const float* x, const int32_t* idx, float* y, int rows, int d, int ldx, int ldy, void* stream) {
+  EFM_REQUIRE(x && idx && y && rows > 0 && d > 0, "gather_rows: bad argument");
+  hipLaunchKernelGGL(gather_rows_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, idx, y, rows, d, ldx, ldy);
+  return efm::check_launch("gather_rows");
+}
+
+int efm_triplet_fwd(const float* a, const float* p, const float* n, float* loss, int rows, int d, int lda, int ldp,
+                    int ldn, float margin, void* stream) {
+  EFM_REQUIRE(a && p && n && loss && rows > 0 && d > 0, "triplet_fwd: bad argument");
+  hipLaunchKernelGGL(triplet_fwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, p, n, loss, rows, d, lda, ldp, ldn, margin);
+  return efm::check_launch("triplet_fwd");
+}
+
+int efm_triplet_bwd(const float* a, const float* p, const float* n, const float* loss, const float* gloss, float* da,
+                    float* dp, float* dn, int rows, int d, int lda, int ldp, int ldn, int ldg, void* stream) {
+  EFM_REQUIRE(a && p && n && loss && gloss && rows > 0 && d > 0, "triplet_bwd: bad argument");
+  hipLaunchKernelGGL(triplet_bwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, p, n, loss, gloss, da, dp, dn, rows, d, lda, ldp, ldn, ldg);
+  return efm::check_launch("triplet_bwd");
+}
+
+int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap, float* s_an, int rows, int d,
+                     int lda, int ldp, int ldn, void* stream) {
+  EFM_REQUIRE(a && p && n && s_ap && s_an && rows > 0 && d > 0, "cosine_pairs: bad argument");
+  hipLaunchKernelGGL(cosine_pairs_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, p, n, s_ap, s_an, rows, d, lda, ldp, ldn);
+  return efm::check_launch("cosine_pairs");
+}
+
+int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream) {
+  EFM_REQUIRE(e && g && rows > 0 && d > 0 && d <= 16384, "gram_cosine: bad argument");
+  hipLaunchKernelGGL(gram_cosine_k, dim3(rows), dim3(256), d * sizeof(float), (hipStream_t)stream, e, g, rows, d, lde);
+  return efm::check_launch("gram_cosine");
+}
+
+int efm_mine_semihard(const float* g, const int32_t* labels, const int32_t* anchor_idx, const int32_t* pos_idx,
+                      int32_t* neg_idx, int n_anchor, int rows, void* stream) {
+  EFM_REQUIRE(g && labels && anchor_idx && pos_idx && neg_idx && n_anchor > 0 && rows > 0, "mine_semihard: bad argument");
+  hipLaunchKernelGGL(mine_semihard_k, dim3((n_anchor + 3) / 4), dim3(256), 0, (hipStream_t)stream, g, labels, anchor_idx, pos_idx, neg_idx, n_anchor, rows);
+  return efm::check_launch("mine_semihard");
+}
+
+int efm_sgd_update(float* w, const float* g, int64_t n, float lr, float wd, float rescale, void* stream) {
+  EFM_REQUIRE(w && g && n > 0 && n % 4 == 0, "sgd_update: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(sgd_k, dim3((unsigned)efm::cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, w, g, (long)(n / 4), lr, wd, rescale);
+  return efm::check_launch("sgd_update");
+}
+
+int efm_adam_update(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float wd, float rescale, int step, void* stream) {
+  EFM_REQUIRE(w && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "adam_update: bad argument");
+  const double c1 = 1.0 - pow((double)beta1, step), c2 = 1.0 - pow((double)beta2, step);
+  const float lr_t = (float)(lr * sqrt(c2) / c1);
+  hipLaunchKernelGGL(adam_k, dim3((unsigned)efm::cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (long)(n / 4), lr_t, beta1, beta2, eps, wd, rescale);
+  return efm::check_launch("adam_update");
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+"""Raw (non-autograd) calls into the HIP library on torch device tensors.
+
+PyTorch is used here for device memory and the current HIP stream only; every computation below is a
+kernel of libefm_hip.so.  Activations are NHWC tensors (B, H, W, Cp) with Cp = pad4(C) and zero pad
+channels; 2-D (rows, Cp) tensors are the H = W = 1 case.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, conv_desc, pad4, pad16  # noqa: F401
+
+_workspace = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.EfmError("efm ops need device tensors (the HIP library is the only compute path)")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise _lib.EfmError("efm ops take float32 / int32 tensors, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise _lib.EfmError("efm ops need contiguous tensors")
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (split-K slabs); never allocated inside a captured region twice."""
+    key = (device.type, device.index)
+    ws = _workspace.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
+        _workspace[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv_weight_shape(d):
+    return (d.n_pad16, d.k_pad)
+
+
+def conv_pack_weights(d, w_oihw):
+    _need_dev(w_oihw)
+    wp = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=w_oihw.device)
+    check(_lib.load().efm_conv_pack_weights(ctypes.byref(d), _p(w_oihw), _p(wp), _stream()), "efm_conv_pack_weights")
+    return wp
+
+
+def conv_pack_weights_into(d, w_oihw, wp):
+    _need_dev(w_oihw, wp)
+    check(_lib.load().efm_conv_pack_weights(ctypes.byref(d), _p(w_oihw), _p(wp), _stream()), "efm_conv_pack_weights")
+
+
+def conv_unpack_weights(d, wp):
+    _need_dev(wp)
+    w = torch.empty((d.cout, d.cin, d.kh, d.kw), dtype=torch.float32, device=wp.device)
+    check(_lib.load().efm_conv_unpack_weights(ctypes.byref(d), _p(wp), _p(w), _stream()), "efm_conv_unpack_weights")
+    return w
+
+
+def conv_make_dgrad_weights(d, wp, out=None):
+    _need_dev(wp, out)
+    if out is None:
+        out = torch.empty((d.dn_pad16, d.dk_pad), dtype=torch.float32, device=wp.device)
+    check(_lib.load().efm_conv_make_dgrad_weights(ctypes.byref(d), _p(wp), _p(out), _stream()), "efm_conv_make_dgrad_weights")
+    return out
+
+
+def conv_fwd(d, x, wp, bias=None, residual=None, out=None):
+    _need_dev(x, wp, bias, residual, out)
+    if out is None:
+        out = torch.empty((d.batch, d.hout, d.wout, d.cout_p), dtype=torch.float32, device=x.device)
+    assert x.numel() == d.batch * d.hin * d.win * d.cin_p, (x.shape, d.batch, d.hin, d.win, d.cin_p)
+    assert out.numel() == d.batch * d.hout * d.wout * d.cout_p
+    assert wp.numel() == d.n_pad16 * d.k_pad
+    assert bias is None or bias.numel() == d.n_pad16
+    assert residual is None or residual.numel() == out.numel()
+    check(_lib.load().efm_conv_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(residual), _p(out), _stream()), "efm_conv_fwd")
+    return out
+
+
+def conv_bwd_data(d, dy, wd, add=None, out=None):
+    _need_dev(dy, wd, add, out)
+    if out is None:
+        out = torch.empty((d.batch, d.hin, d.win, d.cin_p), dtype=torch.float32, device=dy.device)
+    assert dy.numel() == d.batch * d.hout * d.wout * d.cout_p
+    assert out.numel() == d.batch * d.hin * d.win * d.cin_p
+    assert wd.numel() == d.dn_pad16 * d.dk_pad
+    assert add is None or add.numel() == out.numel()
+    check(_lib.load().efm_conv_bwd_data(ctypes.byref(d), _p(dy), _p(wd), _p(add), _p(out), _stream()), "efm_conv_bwd_data")
+    return out
+
+
+def conv_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True):
+    _need_dev(x, dy, dw, dbias)
+    if dw is None:
+        dw = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((d.n_pad16,), dtype=torch.float32, device=x.device)
+    assert x.numel() == d.batch * d.hin * d.win * d.cin_p
+    assert dy.numel() == d.batch * d.hout * d.wout * d.cout_p
+    assert dw.numel() == d.n_pad16 * d.k_pad
+    lib = _lib.load()
+    nbytes = lib.efm_conv_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = workspace(nbytes, x.device)
+    check(lib.efm_conv_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), _p(ws),
+                                  ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_conv_bwd_weight")
+    return dw, (dbias if want_bias else None)
+
+
+# ------------------------------------------------------------------------------------ elementwise
+def nchw_to_nhwc(x, out=None):
+    _need_dev(x, out)
+    b, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((b, h, w, pad4(c)), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_nchw_to_nhwc(_p(x), _p(out), b, c, h, w, _stream()), "efm_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, c, out=None):
+    _need_dev(x, out)
+    b, h, w, cp = x.shape
+    assert cp == pad4(c)
+    if out is None:
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_nhwc_to_nchw(_p(x), _p(out), b, c, h, w, _stream()), "efm_nhwc_to_nchw")
+    return out
+
+
+def mfm_out_channels(c, ways):
+    return 2 * c // 3 if ways == 3 else c // 2
+
+
+def mfm_fwd(x, c, ways=3, out=None):
+    _need_dev(x, out)
+    assert x.shape[-1] == pad4(c)
+    rows = x.numel() // x.shape[-1]
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (pad4(mfm_out_channels(c, ways)),), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_mfm_fwd(_p(x), _p(out), rows, c, ways, _stream()), "efm_mfm_fwd")
+    return out
+
+
+def mfm_bwd(x, dy, c, ways=3, order=_lib.MFM_ORDER_GROUP, add=None, out=None):
+    _need_dev(x, dy, add, out)
+    rows = x.numel() // x.shape[-1]
+    assert dy.numel() == rows * pad4(mfm_out_channels(c, ways))
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().efm_mfm_bwd(_p(x), _p(dy), _p(add), _p(out), rows, c, ways, order, _stream()), "efm_mfm_bwd")
+    return out
+
+
+def maxpool2_fwd(x, c, out=None):
+    _need_dev(x, out)
+    b, h, w, cp = x.shape
+    assert cp == pad4(c)
+    if out is None:
+        out = torch.empty((b, h // 2, w // 2, cp), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_maxpool2_fwd(_p(x), _p(out), b, h, w, c, _stream()), "efm_maxpool2_fwd")
+    return out
+
+
+def maxpool2_bwd(x, dy, c, out=None):
+    _need_dev(x, dy, out)
+    b, h, w, cp = x.shape
+    assert dy.numel() == b * (h // 2) * (w // 2) * cp
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().efm_maxpool2_bwd(_p(x), _p(dy), _p(out), b, h, w, c, _stream()), "efm_maxpool2_bwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ head
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+def _need_rows(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise _lib.EfmError("head ops take 2-D float32 device tensors with unit inner stride")
+
+
+def l2norm_fwd(x, mode=_lib.L2_ROW):
+    _need_rows(x)
+    rows, d = x.shape
+    y = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    norm = torch.empty((rows if mode == _lib.L2_ROW else 1,), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_l2norm_fwd(_p(x), _p(y), _p(norm), rows, d, _ld(x), d, mode, _stream()), "efm_l2norm_fwd")
+    return y, norm
+
+
+def l2norm_bwd(y, norm, dy, mode=_lib.L2_ROW):
+    _need_rows(y, dy)
+    rows, d = y.shape
+    dx = torch.empty((rows, d), dtype=torch.float32, device=y.device)
+    check(_lib.load().efm_l2norm_bwd(_p(y), _p(norm), _p(dy), _p(dx), rows, d, _ld(y), _ld(dy), d, mode, _stream()), "efm_l2norm_bwd")
+    return dx
+
+
+def gather_rows(x, idx):
+    _need_rows(x)
+    assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous()
+    rows, d = idx.numel(), x.shape[1]
+    y = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_gather_rows(_p(x), _p(idx), _p(y), rows, d, _ld(x), d, _stream()), "efm_gather_rows")
+    return y
+
+
+def triplet_fwd(a, p, n, margin):
+    _need_rows(a, p, n)
+    rows, d = a.shape
+    loss = torch.empty((rows,), dtype=torch.float32, device=a.device)
+    check(_lib.load().efm_triplet_fwd(_p(a), _p(p), _p(n), _p(loss), rows, d, _ld(a), _ld(p), _ld(n), float(margin), _stream()), "efm_triplet_fwd")
+    return loss
+
+
+def triplet_bwd(a, p, n, loss, gloss, need_dn=False):
+    _need_rows(a, p, n)
+    rows, d = a.shape
+    da = torch.empty((rows, d), dtype=torch.float32, device=a.device)
+    dp = torch.empty_like(da)
+    dn = torch.empty_like(da) if need_dn else None
+    check(_lib.load().efm_triplet_bwd(_p(a), _p(p), _p(n), _p(loss), _p(gloss), _p(da), _p(dp), _p(dn), rows, d,
+                                      _ld(a), _ld(p), _ld(n), d, _stream()), "efm_triplet_bwd")
+    return da, dp, dn
+
+
+def cosine_pairs(a, p, n):
+    _need_rows(a, p, n)
+    rows, d = a.shape
+    s_ap = torch.empty((rows,), dtype=torch.float32, device=a.device)
+    s_an = torch.empty_like(s_ap)
+    check(_lib.load().efm_cosine_pairs(_p(a), _p(p), _p(n), _p(s_ap), _p(s_an), rows, d, _ld(a), _ld(p), _ld(n), _stream()), "efm_cosine_pairs")
+    return s_ap, s_an
+
+
+def gram_cosine(e):
+    _need_rows(e)
+    rows, d = e.shape
+    g = torch.empty((rows, rows), dtype=torch.float32, device=e.device)
+    check(_lib.load().efm_gram_cosine(_p(e), _p(g), rows, d, _ld(e), _stream()), "efm_gram_cosine")
+    return g
+
+
+def mine_semihard(g, labels, anchor_idx, pos_idx):
+    for t in (labels, anchor_idx, pos_idx):
+        assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+    n_anchor, rows = anchor_idx.numel(), g.shape[0]
+    neg = torch.empty((n_anchor,), dtype=torch.int32, device=g.device)
+    check(_lib.load().efm_mine_semihard(_p(g), _p(labels), _p(anchor_idx), _p(pos_idx), _p(neg), n_anchor, rows, _stream()), "efm_mine_semihard")
+    return neg
+
+
+# ------------------------------------------------------------------------------------- optimiser
+def sgd_update(w, g, lr, wd=0.0, rescale=1.0):
+    _need_dev(w, g)
+    check(_lib.load().efm_sgd_update(_p(w), _p(g), w.numel(), float(lr), float(wd), float(rescale), _stream()), "efm_sgd_update")
+
+
+def adam_update(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, rescale=1.0):
+    _need_dev(w, g, m, v)
+    check(_lib.load().efm_adam_update(_p(w), _p(g), _p(m), _p(v), w.numel(), float(lr), float(beta1), float(beta2),
+                                      float(eps), float(wd), float(rescale), int(step), _stream()), "efm_adam_update")

@@ -1,0 +1,169 @@
+/*
+ * efm_hip.h — C ABI of the MI355X (gfx950) hot path of the EFM triplet-loss trainer.
+ *
+ * The reference (joannhsiao/Improving_Face_recognition_Performance_using_Triplet_Loss)
+ * has NO plugin / FFI / custom-op layer: its hot path is a sequence of stock MXNet
+ * operator calls.  Every entry point below therefore replaces an MXNet operator *call
+ * site* of the reference; the call site is cited as "ref: file:line".
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns every buffer (activations, packed weights, workspaces);
+ *     the library never allocates or frees device memory and keeps no mutable state;
+ *   - every function enqueues asynchronously on the hipStream_t passed as `stream`
+ *     (a void* here so that the header needs no HIP include) and returns at once;
+ *   - return value: 0 = EFM_OK, negative = EFM_E_*; efm_last_error_string() gives the
+ *     thread-local text of the last failure.  No C++ exception crosses this boundary.
+ *
+ * Tensor layouts (all fp32)
+ *   - activations: NHWC with the channel stride padded to a multiple of 4,
+ *       x[b][h][w][cp], cp = efm_pad4(c); channels c..cp-1 are ZERO (an invariant every
+ *       kernel keeps: pads are written as zeros, never read as data).
+ *   - packed conv weights ("OHWI, padded"): w[n][k], n < n_pad16 = pad16(cout),
+ *       k = (kh*KW + kw)*cin_p + ci < k_pad = pad16(KH*KW*cin_p); everything outside
+ *       (cout, KH, KW, cin) is zero.  MXNet's own layout is (cout, cin, KH, KW)
+ *       (ref: efm_symbol.py:32 `mx.symbol.Convolution`); efm_conv_pack_weights /
+ *       efm_conv_unpack_weights convert between the two.
+ */
+#ifndef EFM_HIP_H_
+#define EFM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFM_OK 0
+#define EFM_E_INVALID (-1)     /* bad argument / shape the kernels do not support */
+#define EFM_E_LAUNCH (-2)      /* hipGetLastError() after a launch was not hipSuccess */
+#define EFM_E_WORKSPACE (-3)   /* workspace pointer null or too small */
+
+#define EFM_ABI_VERSION 1
+
+/* MFM tie rule: which operand wins when two slices are exactly equal.
+ * ORDER_GROUP:  maximum(maximum(s0,s1), s2)  (ref: efm_symbol.py:70-73, lightcnn.py:23-26)
+ * ORDER_RES:    maximum(s2, maximum(s0,s1))  (ref: efm_symbol.py:26-29)
+ * MXNet's backward of maximum/minimum(lhs,rhs) sends the gradient to lhs on a tie. */
+#define EFM_MFM_ORDER_GROUP 0
+#define EFM_MFM_ORDER_RES 1
+
+/* L2-normalisation modes. ROW: y[i] = x[i]/||x[i]||   (ref: final_efm.py:240-243)
+ *                         FROBENIUS: y = x/||x||_F     (ref: train_efm.py:241) */
+#define EFM_L2_ROW 0
+#define EFM_L2_FROBENIUS 1
+
+int efm_version(void);
+const char* efm_last_error_string(void);
+
+static inline int efm_pad4(int c) { return (c + 3) & ~3; }
+static inline int efm_pad16(int c) { return (c + 15) & ~15; }
+
+/* ------------------------------------------------------------------------------------
+ * Convolution (stride 1, cross-correlation, bias) — ref: mx.symbol.Convolution at
+ * efm_symbol.py:32,41,54,62,65,67 and nn.Conv2D at lightcnn.py:14-15,47-48.
+ * Also serves FullyConnected (ref: efm_symbol.py:94 fc1, pre-trained_efm_v3.py:181
+ * Dense(128)) as a KHxKW "valid" convolution whose output map is 1x1.
+ * ------------------------------------------------------------------------------------ */
+typedef struct efm_conv_desc {
+  int32_t batch;
+  int32_t hin, win, cin, cin_p;      /* input map; cin_p = efm_pad4(cin) = channel stride of x */
+  int32_t hout, wout, cout, cout_p;  /* output map; cout_p = efm_pad4(cout) = channel stride of y */
+  int32_t kh, kw, pad_h, pad_w;
+  int32_t n_pad16;                   /* rows of the packed weight = efm_pad16(cout) */
+  int32_t k_pad;                     /* row length of the packed weight = efm_pad16(kh*kw*cin_p) */
+  int32_t dn_pad16;                  /* rows of the packed dgrad weight = efm_pad16(cin) */
+  int32_t dk_pad;                    /* its row length = efm_pad16(kh*kw*cout_p) */
+} efm_conv_desc;
+
+/* Fill every derived field (hout = hin + 2*pad_h - kh + 1, paddings, packed sizes). */
+int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, int cout,
+                       int kh, int kw, int pad_h, int pad_w);
+
+size_t efm_conv_weight_elems(const efm_conv_desc* d);        /* n_pad16 * k_pad  */
+size_t efm_conv_dgrad_weight_elems(const efm_conv_desc* d);  /* dn_pad16 * dk_pad */
+size_t efm_conv_wgrad_workspace_bytes(const efm_conv_desc* d);
+
+/* (cout,cin,KH,KW) <-> packed. */
+int efm_conv_pack_weights(const efm_conv_desc* d, const float* w_oihw, float* w_packed, void* stream);
+int efm_conv_unpack_weights(const efm_conv_desc* d, const float* w_packed, float* w_oihw, void* stream);
+/* packed forward weight -> packed, tap-flipped, transposed weight used by efm_conv_bwd_data. */
+int efm_conv_make_dgrad_weights(const efm_conv_desc* d, const float* w_packed, float* wd_packed, void* stream);
+
+/* y = conv(x, w) + bias (+ residual).  bias[n_pad16] or NULL; residual has y's shape or NULL
+ * (ref: efm_symbol.py:42 `data + conv_r1`). */
+int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
+                 const float* residual, float* y, void* stream);
+/* dx = conv_transpose(dy, w) (+ add).  `add` has dx's shape or NULL (skip-path gradient). */
+int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed,
+                      const float* add, float* dx, void* stream);
+/* dw_packed[n][k] = sum_m dy[m][n] * im2col(x)[m][k]; dbias[n] = sum_m dy[m][n] (dbias may be NULL).
+ * Deterministic: split over m into workspace slabs, then a fixed-order reduction. */
+int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed,
+                        float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).
+ * ------------------------------------------------------------------------------------ */
+int efm_nchw_to_nhwc(const float* x_nchw, float* y_nhwc, int batch, int c, int h, int w, void* stream);
+int efm_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int batch, int c, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * MFM — SliceChannel + maximum/minimum + Concat.
+ * ways = 3: y[:, 0:c/3] = max(x0,x1,x2), y[:, c/3:2c/3] = min(x0,x1,x2)
+ *           (ref: efm_symbol.py:25-30,34-39,55-60,69-74,96-101; lightcnn.py:22-27).
+ * ways = 2: y = max(x[:, :c/2], x[:, c/2:])   (ref: efm_symbol.py:63-64,76-77).
+ * x: [rows][efm_pad4(c)], y: [rows][efm_pad4(c_out)], c_out = 2c/3 or c/2.
+ * bwd: dx = dMFM(x, dy) (+ add), gradient to the arg-max / arg-min slice.
+ * ------------------------------------------------------------------------------------ */
+int efm_mfm_fwd(const float* x, float* y, int64_t rows, int c, int ways, void* stream);
+int efm_mfm_bwd(const float* x, const float* dy, const float* add, float* dx, int64_t rows, int c,
+                int ways, int order, void* stream);
+
+/* Max pooling 2x2 stride 2, 'valid' (floor) — ref: efm_symbol.py:78, lightcnn.py:83. */
+int efm_maxpool2_fwd(const float* x, float* y, int batch, int h, int w, int c, void* stream);
+int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Embedding head / loss (dense row-major matrices, leading dimension = ld* floats).
+ * ------------------------------------------------------------------------------------ */
+/* ref: train_efm.py:241 (FROBENIUS), final_efm.py:240-243 (ROW).  norm_out: [rows] (ROW) or [1]. */
+int efm_l2norm_fwd(const float* x, float* y, float* norm_out, int rows, int d, int ldx, int ldy, int mode, void* stream);
+int efm_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx, int rows, int d,
+                   int ldy, int lddy, int lddx, int mode, void* stream);
+/* y[i] = x[idx[i]]  — the reference's negative pick copies rows (ref: train_efm.py:234-239). */
+int efm_gather_rows(const float* x, const int32_t* idx, float* y, int rows, int d, int ldx, int ldy, void* stream);
+/* loss[i] = max(0, sum_d (p-a)^2 - sum_d (n-a)^2 + margin) — gluon.loss.TripletLoss
+ * (ref: train_efm.py:210,241; pre-trained_efm_v3.py:183,210). */
+int efm_triplet_fwd(const float* a, const float* p, const float* n, float* loss, int rows, int d,
+                    int lda, int ldp, int ldn, float margin, void* stream);
+/* da/dp/dn may each be NULL (dn is NULL in the reference: negatives are detached). */
+int efm_triplet_bwd(const float* a, const float* p, const float* n, const float* loss, const float* gloss,
+                    float* da, float* dp, float* dn, int rows, int d, int lda, int ldp, int ldn, int ldg,
+                    void* stream);
+/* s_ap[i] = cos(a_i,p_i), s_an[i] = cos(a_i,n_i) — cosine_dist (ref: train_efm.py:26-34). */
+int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap, float* s_an, int rows,
+                     int d, int lda, int ldp, int ldn, void* stream);
+/* g[i][j] = cos(e_i, e_j): the batch-all-pairs cosine matrix (north_star mining path; no reference). */
+int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream);
+/* Semi-hard negative per (anchor i, positive pos[i]) from the cosine matrix g[rows][rows]:
+ * d = 1 - g; pick argmin_{label!=, d_an > d_ap} d_an, else argmax_{label!=} d_an (TF-addons rule).
+ * neg_idx[i] = -1 when the batch holds a single identity. */
+int efm_mine_semihard(const float* g, const int32_t* labels, const int32_t* anchor_idx,
+                      const int32_t* pos_idx, int32_t* neg_idx, int n_anchor, int rows, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser on the flat packed parameter buffer.
+ * SGD: w -= lr*(rescale*g + wd*w)                    (ref: pre-trained_efm_v3.py:185,212)
+ * Adam (MXNet form): g' = rescale*g + wd*w; m,v EMA; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
+ *                                                    (ref: train_efm.py:213, mutli_gpu_v3.py:159)
+ * ------------------------------------------------------------------------------------ */
+int efm_sgd_update(float* w, const float* g, int64_t n, float lr, float wd, float rescale, void* stream);
+int efm_adam_update(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float wd, float rescale, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFM_HIP_H_ */

@@ -1,0 +1,67 @@
+"""CPU ORACLE #2 (test infrastructure, NOT product code) — torch-CPU restatement of the reference graph.
+
+Independent of oracle/efm_oracle.py: built from torch.nn.functional ops (oneDNN convolutions) and torch
+autograd, so the two restatements protect each other against typos (they cannot protect against a shared
+wrong [MX-assumed] reading of MXNet — parity with MXNet itself stays UNPINNED, see efm_oracle.py).
+It is also the `cpu_baseline` ("port") that bench.py times on the GPU box's host cores.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import torch
+import torch.nn.functional as F
+
+GROUPS = [(0, 99, 5, 2, "1", 0), (99, 198, 3, 1, "2", 1), (198, 387, 3, 1, "3", 2), (387, 261, 3, 1, "4", 3),
+          (261, 261, 3, 1, "5", 4)]  # ref: efm_symbol.py:84-92
+
+
+def mfm3(x):
+    # ref: efm_symbol.py:25-30 — torch.maximum/minimum split a tie gradient 50/50, MXNet gives it to the lhs;
+    # ties have measure zero on continuous data, tie behaviour is pinned in the NumPy oracle's KATs instead.
+    s0, s1, s2 = torch.chunk(x, 3, dim=1)
+    return torch.cat([torch.maximum(torch.maximum(s0, s1), s2), torch.minimum(torch.minimum(s0, s1), s2)], dim=1)
+
+
+def mfm2(x):
+    s0, s1 = torch.chunk(x, 2, dim=1)
+    return torch.maximum(s0, s1)
+
+
+def res_block(p, data, lname):
+    # ref: efm_symbol.py:22-44
+    e = mfm3(data)
+    c = F.conv2d(e, p["conv%s_res_weight" % lname], p["conv%s_res_bias" % lname], padding=1)
+    e = mfm3(c)
+    c = F.conv2d(e, p["conv%s_res_r_weight" % lname], p["conv%s_res_r_bias" % lname], padding=1)
+    return data + c
+
+
+def efm29_forward(p, x):
+    """(B,C,H,W) -> 342-d feature; `p` maps MXNet parameter names to tensors."""
+    cur = x
+    for num_r, num, k, pad, layer, tar in GROUPS:
+        if num_r > 0:
+            for i in range(tar):
+                cur = res_block(p, cur, layer if i == 0 else layer + str(i))
+            cur = mfm3(F.conv2d(cur, p["conv%s_r_weight" % layer], p["conv%s_r_bias" % layer]))
+        cur = F.conv2d(cur, p["conv%s_weight" % layer], p["conv%s_bias" % layer], padding=pad)
+        cur = F.max_pool2d(mfm3(cur), 2, 2)  # ceil_mode False = MXNet 'valid'
+    fc1 = F.linear(cur.flatten(1), p["fc1_weight"], p["fc1_bias"])
+    return mfm3(fc1)
+
+
+def triplet_loss(a, p, n, margin):
+    return F.relu(((p - a) ** 2 - (n - a) ** 2).sum(dim=1) + margin)
+
+
+def train_step(p, w_head, x, neg_idx, margin):
+    """Reference-layout step (see efm_oracle.train_step_loss): returns (loss vector, emb, feat); gradients land in
+    .grad of every tensor of `p` and of `w_head`."""
+    feat = efm29_forward(p, x)
+    yn = feat / feat.norm(dim=1, keepdim=True)
+    emb = yn @ w_head.t()
+    h = x.shape[0] // 2
+    a, pos = emb[:h], emb[h:]
+    n = emb[neg_idx].detach()  # negatives are copied through NumPy in the reference (train_efm.py:238-239)
+    loss = triplet_loss(a, pos, n, margin)
+    loss.sum().backward()  # vector backward = ones head-gradient
+    return loss.detach(), emb.detach(), feat.detach()

@@ -1,0 +1,222 @@
+"""GPU parity of every HIP kernel behind include/efm_hip.h against the CPU oracle (oracle/efm_oracle.py).
+
+Tolerance: the north star asks for 1e-3 relative fp32 end to end; single kernels are held to 2e-4 of the
+largest reference magnitude (fp32 MFMA = k-ordered fmaf chain, error ~1e-7 * sum|a*b|).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import efm_oracle as O
+from tests.util import dev, from_nhwc, rand, rel_err, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops as _ops
+    return _ops
+
+
+def test_layout_roundtrip(ops):
+    x = rand((3, 5, 7, 6), 0)
+    y = to_nhwc(x)
+    assert tuple(y.shape) == (3, 7, 6, 8)
+    ref = np.zeros((3, 7, 6, 8))
+    ref[..., :5] = x.transpose(0, 2, 3, 1)
+    assert rel_err(y.cpu().numpy(), ref) < 1e-7
+    assert rel_err(from_nhwc(y, 5), x.astype(np.float32)) < 1e-7
+
+
+CONV_CASES = [
+    # batch, h, w, cin, cout, k, pad
+    (2, 12, 10, 3, 99, 5, 2),     # conv1-like (cin_p = 4, four taps per K step)
+    (2, 9, 11, 44, 99, 3, 1),     # conv2_res
+    (3, 8, 8, 66, 66, 3, 1),      # conv2_res_r (cin_p 68: K pieces straddle taps)
+    (2, 7, 7, 66, 99, 1, 0),      # 1x1
+    (2, 6, 5, 132, 387, 3, 1),    # two channel blocks (25 tiles)
+    (1, 5, 5, 258, 258, 3, 1),    # 17 tiles -> 9+8
+    (5, 3, 3, 174, 513, 3, 0),    # fc1 as a 3x3 'valid' conv, output 1x1
+    (7, 1, 1, 342, 128, 1, 0),    # embedding head Dense(128)
+    (2, 14, 14, 172, 387, 3, 1),
+]
+
+
+@pytest.mark.parametrize("mt", [1, 2])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(ops, case, mt):
+    b, h, w, cin, cout, k, pad = case
+    os.environ["EFM_CONV_MT"] = str(mt)
+    try:
+        x = rand((b, cin, h, w), 1)
+        wt = rand((cout, cin, k, k), 2, 0.2)
+        bias = rand((cout,), 3)
+        d = ops.conv_desc(b, h, w, cin, cout, k, k, pad, pad)
+        xd = to_nhwc(x)
+        wp = ops.conv_pack_weights(d, dev(wt))
+        assert rel_err(ops.conv_unpack_weights(d, wp).cpu().numpy(), wt.astype(np.float32)) < 1e-7
+        bp = torch.zeros(d.n_pad16, device="cuda")
+        bp[:cout] = dev(bias)
+        ref = O.conv2d(x, wt, bias, (pad, pad))
+        y = ops.conv_fwd(d, xd, wp, bp)
+        assert rel_err(from_nhwc(y, cout), ref) < TOL
+        # pad channels stay zero
+        assert float(y[..., cout:].abs().max()) == 0.0 if d.cout_p > cout else True
+        # residual epilogue
+        res = rand(ref.shape, 4)
+        y2 = ops.conv_fwd(d, xd, wp, bp, residual=to_nhwc(res))
+        assert rel_err(from_nhwc(y2, cout), ref + res) < TOL
+        # backward
+        dy = rand(ref.shape, 5)
+        dx_ref, dw_ref, db_ref = O.conv2d_bwd(x, wt, dy, (pad, pad))
+        dyd = to_nhwc(dy)
+        wd = ops.conv_make_dgrad_weights(d, wp)
+        dx = ops.conv_bwd_data(d, dyd, wd)
+        assert rel_err(from_nhwc(dx, cin), dx_ref) < TOL
+        if d.cin_p > cin:
+            assert float(dx[..., cin:].abs().max()) == 0.0
+        add = rand(x.shape, 6)
+        dx2 = ops.conv_bwd_data(d, dyd, wd, add=to_nhwc(add))
+        assert rel_err(from_nhwc(dx2, cin), dx_ref + add) < TOL
+        dw, db = ops.conv_bwd_weight(d, xd, dyd)
+        assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < TOL
+        assert rel_err(db[:cout].cpu().numpy(), db_ref) < TOL
+        # packed-gradient pads are exactly zero (keeps the zero-pad invariant of the packed weights under SGD)
+        dwm = dw.clone()
+        ops.conv_pack_weights_into(d, ops.conv_unpack_weights(d, dw), dwm)
+        assert torch.equal(dwm, dw)
+        assert float(db[cout:].abs().max()) == 0.0 if d.n_pad16 > cout else True
+    finally:
+        os.environ.pop("EFM_CONV_MT", None)
+
+
+def test_conv_wgrad_deterministic(ops):
+    b, h, w, cin, cout = 4, 28, 28, 88, 198
+    d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+    xd = to_nhwc(rand((b, cin, h, w), 1))
+    dyd = to_nhwc(rand((b, cout, h, w), 2))
+    dw1, db1 = ops.conv_bwd_weight(d, xd, dyd)
+    dw1, db1 = dw1.clone(), db1.clone()
+    dw2, db2 = ops.conv_bwd_weight(d, xd, dyd)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("c,rows", [(99, (2, 5, 4)), (66, (3, 4, 4)), (513, (6,)), (387, (1, 3, 3))])
+def test_mfm3(ops, c, rows):
+    shape = (rows[0], c) + tuple(rows[1:]) if len(rows) == 3 else (rows[0], c, 1, 1)
+    x = rand(shape, 7)
+    # force exact ties so that the tie rule is exercised
+    x[0, : c // 3] = x[0, c // 3: 2 * c // 3]
+    x[-1, 2 * (c // 3):] = x[-1, : c // 3]
+    xd = to_nhwc(x)
+    y = ops.mfm_fwd(xd, c, 3)
+    co = 2 * c // 3
+    assert rel_err(from_nhwc(y, co), O.mfm3(x)) < 1e-7
+    if y.shape[-1] > co:
+        assert float(y[..., co:].abs().max()) == 0.0
+    dy = rand(O.mfm3(x).shape, 8)
+    add = rand(x.shape, 9)
+    for order in (O.ORDER_GROUP, O.ORDER_RES):
+        dx = ops.mfm_bwd(xd, to_nhwc(dy), c, 3, order)
+        assert rel_err(from_nhwc(dx, c), O.mfm3_bwd(x, dy, order)) < 1e-7
+        dx2 = ops.mfm_bwd(xd, to_nhwc(dy), c, 3, order, add=to_nhwc(add))
+        assert rel_err(from_nhwc(dx2, c), O.mfm3_bwd(x, dy, order) + add) < 1e-6
+
+
+def test_mfm2(ops):
+    x = rand((2, 96, 5, 5), 10)
+    x[0, :48] = x[0, 48:]
+    xd = to_nhwc(x)
+    y = ops.mfm_fwd(xd, 96, 2)
+    assert rel_err(from_nhwc(y, 48), O.mfm2(x)) < 1e-7
+    dy = rand((2, 48, 5, 5), 11)
+    dx = ops.mfm_bwd(xd, to_nhwc(dy), 96, 2)
+    assert rel_err(from_nhwc(dx, 96), O.mfm2_bwd(x, dy)) < 1e-7
+
+
+@pytest.mark.parametrize("h,w,c", [(8, 8, 66), (7, 7, 174), (5, 6, 44), (112, 112, 66)])
+def test_maxpool2(ops, h, w, c):
+    b = 2
+    x = rand((b, c, h, w), 12)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = 5.0  # tie inside a window -> first wins
+    xd = to_nhwc(x)
+    y = ops.maxpool2_fwd(xd, c)
+    ref = O.maxpool2(x)
+    assert rel_err(from_nhwc(y, c), ref) < 1e-7
+    dy = rand(ref.shape, 13)
+    dx = torch.full_like(xd, float("nan"))  # poison: every element must be written
+    ops.maxpool2_bwd(xd, to_nhwc(dy), c, out=dx)
+    assert rel_err(from_nhwc(dx, c), O.maxpool2_bwd(x, dy)) < 1e-7
+
+
+@pytest.mark.parametrize("rows,d", [(5, 128), (128, 342), (3, 684), (16, 100)])
+def test_l2norm(ops, rows, d):
+    x = rand((rows, d), 14)
+    dy = rand((rows, d), 15)
+    y, n = ops.l2norm_fwd(dev(x), 0)
+    yr, nr = O.l2norm_row(x)
+    assert rel_err(y.cpu().numpy(), yr) < 1e-6 and rel_err(n.cpu().numpy(), nr) < 1e-6
+    dx = ops.l2norm_bwd(y, n, dev(dy), 0)
+    assert rel_err(dx.cpu().numpy(), O.l2norm_row_bwd(yr, nr, dy)) < 1e-5
+    y, n = ops.l2norm_fwd(dev(x), 1)
+    yf, nf = O.l2norm_frob(x)
+    assert rel_err(y.cpu().numpy(), yf) < 1e-6 and abs(float(n[0]) - nf) / nf < 1e-6
+    dx = ops.l2norm_bwd(y, n, dev(dy), 1)
+    assert rel_err(dx.cpu().numpy(), O.l2norm_frob_bwd(yf, nf, dy)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,d,margin", [(7, 128, 0.2), (128, 342, 0.5), (33, 2, 0.2)])
+def test_triplet_and_cosine(ops, rows, d, margin):
+    a, p, n = rand((rows, d), 16, 0.2), rand((rows, d), 17, 0.2), rand((rows, d), 18, 0.2)
+    n[0] = a[0] * 50  # a row whose loss is clamped to zero -> gradient gate
+    loss = ops.triplet_fwd(dev(a), dev(p), dev(n), margin)
+    lr = O.triplet_loss(a, p, n, margin)
+    assert (lr == 0).any() and (lr > 0).any()
+    assert rel_err(loss.cpu().numpy(), lr) < 1e-5
+    g = rand((rows,), 19)
+    da, dp, dn = ops.triplet_bwd(dev(a), dev(p), dev(n), loss, dev(g), need_dn=True)
+    ra, rp, rn = O.triplet_loss_bwd(a, p, n, lr, g)
+    assert rel_err(da.cpu().numpy(), ra) < 1e-5 and rel_err(dp.cpu().numpy(), rp) < 1e-5
+    assert rel_err(dn.cpu().numpy(), rn) < 1e-5
+    s_ap, s_an = ops.cosine_pairs(dev(a), dev(p), dev(n))
+    r_ap, r_an = O.cosine_dist(a, p, n)
+    assert rel_err(s_ap.cpu().numpy(), r_ap) < 1e-5 and rel_err(s_an.cpu().numpy(), r_an) < 1e-5
+
+
+def test_gather_gram_mining(ops):
+    rows, d = 64, 128
+    e = rand((rows, d), 20)
+    labels = (np.arange(rows) // 4).astype(np.int32)
+    idx = np.array([5, 0, 63, 7], dtype=np.int32)
+    got = ops.gather_rows(dev(e), torch.as_tensor(idx).cuda())
+    assert rel_err(got.cpu().numpy(), e[idx].astype(np.float32)) < 1e-7
+    g = ops.gram_cosine(dev(e))
+    gr = O.gram_cosine(e)
+    assert rel_err(g.cpu().numpy(), gr) < 1e-5
+    anchor = np.arange(rows, dtype=np.int32)
+    pos = (anchor // 4 * 4 + (anchor + 1) % 4).astype(np.int32)
+    neg = ops.mine_semihard(g, torch.as_tensor(labels).cuda(), torch.as_tensor(anchor).cuda(), torch.as_tensor(pos).cuda())
+    ref = O.mine_semihard(g.cpu().numpy().astype(np.float64), labels, anchor, pos)
+    assert np.array_equal(neg.cpu().numpy(), ref)
+    # single identity -> -1
+    one = ops.mine_semihard(g, torch.zeros(rows, dtype=torch.int32).cuda(), torch.as_tensor(anchor).cuda(), torch.as_tensor(pos).cuda())
+    assert (one.cpu().numpy() == -1).all()
+
+
+def test_optimisers(ops):
+    n = 1000
+    w, g = rand((n,), 21), rand((n,), 22)
+    wd_ = dev(w)
+    ops.sgd_update(wd_, dev(g), 0.01, 1e-5, 1.0 / 64)
+    assert rel_err(wd_.cpu().numpy(), O.sgd_step(w, g, 0.01, 1e-5, 1.0 / 64)) < 1e-6
+    wd_, m, v = dev(w), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    wr, mr, vr = w.copy(), np.zeros(n), np.zeros(n)
+    for t in (1, 2, 3):
+        ops.adam_update(wd_, dev(g), m, v, 2.4e-4, t, wd=1e-5, rescale=1.0 / 64)
+        wr, mr, vr = O.adam_step(wr, g, mr, vr, t, 2.4e-4, 1e-5, 1.0 / 64)
+    assert rel_err(wd_.cpu().numpy(), wr) < 1e-6
