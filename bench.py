@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: triplets/s of the EFM-29 triplet training step, 112x112x3, 256 images per GPU, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one resident synthetic batch: forward of [128 anchors ; 128 positives]
+-> in-batch negatives -> TripletLoss -> backward -> (N>1: RCCL all-reduce of the flat gradient, overlapped)
+-> SGD update.  Inputs are generated on the device before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_STEP = 15256522908  # SURVEY.md §8d / BASELINE.md §2: 3*fwd - dgrad(conv1), EFM-29 @112, unpadded
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE: 256)")
+    ap.add_argument("--image", type=int, default=112)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    return ap.parse_args()
+
+
+def dominant_kernel_roofline(trainer, torch, iters=5):
+    """Times, with HIP events on the launch stream, the launches of the conv implicit-GEMM kernel that carries the
+    most work of the step: conv2 (66->198, 3x3, 56x56) forward.  Algorithmic flops = unpadded 2*M*N*K."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    step = [s for s in trainer.plan.steps if s.op == "conv" and s.pname == "conv2"][0]
+    d = step.desc
+    v = trainer.plan.views(trainer.flat)
+    x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=trainer.device)
+    x[..., d.cin:] = 0
+    y = torch.empty((d.batch, d.hout, d.wout, d.cout_p), device=trainer.device)
+    w, b = v["conv2_weight"], v["conv2_bias"]
+    for _ in range(2):
+        ops.conv_fwd(d, x, w, b, out=y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv_fwd(d, x, w, b, out=y)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_fwd_k<2,13> (conv2 forward, 66->198 3x3 @56x56, B=%d)" % d.batch,
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(batch, image, torch):
+    """The CPU restatement of the reference graph (oracle/efm_oracle_torch.py, torch-CPU fp32 / oneDNN) timed on this
+    box's host cores on a bounded sample: `batch` images per step, 1 warm-up + 2 timed steps."""
+    from oracle import efm_oracle as O
+    from oracle import efm_oracle_torch as OT
+    threads = torch.get_num_threads()
+    shapes = O.efm29_param_shapes(3, image)
+    g = torch.Generator().manual_seed(0)
+    p = {}
+    for name, shp in shapes.items():
+        if name.endswith("_bias"):
+            p[name] = torch.zeros(shp, requires_grad=True)
+        else:
+            s = O.xavier_uniform_scale(shp)
+            p[name] = ((torch.rand(shp, generator=g) * 2 - 1) * s).requires_grad_(True)
+    wh = ((torch.rand((128, 342), generator=g) * 2 - 1) * O.xavier_uniform_scale((128, 342))).requires_grad_(True)
+    x = torch.rand((batch, 3, image, image), generator=g)
+    h = batch // 2
+    neg = (torch.arange(h) + 1) % h
+    times = []
+    for i in range(3):
+        for t in list(p.values()) + [wh]:
+            t.grad = None
+        t0 = time.perf_counter()
+        OT.train_step(p, wh, x, neg, 0.2)
+        with torch.no_grad():
+            for t in list(p.values()) + [wh]:
+                t -= 2.4e-4 * (t.grad / h + 1e-5 * t)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(h / dt, 3), "unit": "triplets/s", "cores": threads, "kind": "port",
+            "sample": "torch-CPU fp32 restatement (oracle/efm_oracle_torch.py) of the same EFM-29 step on %d images of "
+                      "%dx%dx3 (= %d triplets), 1 warm-up + 2 timed steps, median %.2f s/step" % (batch, image, image, h, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+
+    tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42)
+    labels = synth.parity_labels(args.batch, rank=rank)
+    batches = []
+    for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step
+        x = synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device)
+        neg = synth.negative_indices(labels, 77 + 1000 * rank + s).to(device)
+        batches.append((x, neg))
+
+    for i in range(args.warmup):
+        tr.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = tr.step(*batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_mean = float(loss.mean().item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        triplets = world * (args.batch // 2) * args.steps / dt
+        images = 2 * triplets
+        out = {
+            "metric": "triplets/sec (whole node) EFM 112x112 bs256/GPU", "value": round(triplets, 2), "unit": "triplets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: EFM-29 128-d embedding, %d images/GPU of %dx%dx3, fp32, "
+                                   "fwd+bwd+SGD, reference batch layout (1 triplet per anchor)" % (args.batch, args.image, args.image),
+                       "images_per_gpu": args.batch, "parallelism": "dp%d" % world},
+            "images_per_s": round(images, 1),
+            "step_mfma_roofline_frac": round(images / world * FLOP_PER_IMAGE_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "loss": round(loss_mean, 6),
+        }
+        out["roofline"] = dominant_kernel_roofline(tr, torch)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.image, torch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -341,12 +341,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
 
 // out[i] = sum_s ws[s*stride + i], fixed order (deterministic).  n4 = element count / 4.
 __global__ void __launch_bounds__(256) slab_reduce_k(const float* __restrict__ ws, float* __restrict__ out,
-                                                     long n4, long stride4, int splits) {
+                                                     long n4, long stride4, int splits, int accumulate) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const f32x4* w = reinterpret_cast<const f32x4*>(ws);
   f32x4 s = w[i];
   for (int k = 1; k < splits; ++k) s += w[(long)k * stride4 + i];
+  if (accumulate) s += reinterpret_cast<f32x4*>(out)[i];
   reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
@@ -590,7 +591,7 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
 }
 
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && x && dy && dw_packed, "conv_bwd_weight: null argument");
   const WgradPlan pl = plan_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
@@ -613,7 +614,7 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   if (rc != EFM_OK) return rc;
   const long n4 = (long)d->n_pad16 * d->k_pad / 4;
   hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(n4, 256)), dim3(256), 0, s, (const float*)workspace,
-                     dw_packed, n4, n4, pl.splits);
+                     dw_packed, n4, n4, pl.splits, accumulate);
   rc = efm::check_launch("conv_wgrad_reduce");
   if (rc != EFM_OK) return rc;
   if (dbias) {
@@ -624,7 +625,7 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
     if (rc != EFM_OK) return rc;
     const long b4 = d->n_pad16 / 4;
     hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(b4, 256)), dim3(256), 0, s, (const float*)part, dbias,
-                       b4, b4, pl.chunks);
+                       b4, b4, pl.chunks, accumulate);
     rc = efm::check_launch("conv_bias_reduce");
   }
   return rc;

@@ -1,0 +1,76 @@
+"""EFM-29 network definition with the reference's builder names and signatures.
+
+Drop-in for the net-builder half of the reference's efm_symbol.py (res_block :22-44, group :46-79,
+multi_gpu :81-110, get_net :112-123) — same call signatures, same parameter names
+(`conv1_weight`, `conv2_res_weight`, `conv31_res_r_bias`, `fc1_weight`, ...), but the nodes are
+`graph.Sym`s that `plan.Plan` lowers onto HIP kernels instead of MXNet symbols.
+"""
+from . import graph as G
+
+
+def _mfm(data, channels, order, name):
+    # 3-way EFM when the channel count divides by 3, LightCNN's 2-way MFM otherwise (ref: efm_symbol.py:48,68)
+    return G.MFM(data, 3 if channels % 3 == 0 else 2, order, name=name)
+
+
+def res_block(data, num_r, layer):
+    """data + conv3x3_{->2num_r/3}(EFM(conv3x3_{->num_r}(EFM(data))))  (ref: efm_symbol.py:22-44)."""
+    num_r1 = int(num_r * (2. / 3.))
+    e = G.MFM(data, 3, G.ORDER_RES, name="efm%s_res_in" % layer)
+    conv_r = G.Convolution(e, num_r, (3, 3), name="conv%s_res" % layer, pad=(1, 1))
+    e = G.MFM(conv_r, 3, G.ORDER_RES, name="efm%s_res" % layer)
+    conv_r1 = G.Convolution(e, num_r1, (3, 3), name="conv%s_res_r" % layer, pad=(1, 1))
+    return data + conv_r1
+
+
+def group(data, num_r, num, kernel, stride, pad, layer, tar_num=0):
+    """[res_block x tar_num -> conv1x1(num_r) -> MFM] -> conv kxk(num) -> MFM -> maxpool 2x2 (ref: efm_symbol.py:46-79)."""
+    if num_r > 0:
+        res = data
+        if num_r % 3 == 0:
+            for x in range(tar_num):
+                res = res_block(res, num_r, layer if x == 0 else layer + str(x))
+        conv_r = G.Convolution(res, num_r, (1, 1), name="conv%s_r" % layer)
+        data = _mfm(conv_r, num_r, G.ORDER_RES, "efm%s_r" % layer)
+    conv = G.Convolution(data, num, kernel, name="conv%s" % layer, pad=pad, stride=stride)
+    mfm = _mfm(conv, num, G.ORDER_GROUP, "efm%s" % layer)
+    return G.Pooling(mfm, name="pool%s" % layer)
+
+
+def efm_feature(data, fc_hidden=513):
+    """Five groups -> fc1 -> EFM: returns (342-d feature, raw fc1) (ref: efm_symbol.py:84-101)."""
+    pool1 = group(data, 0, 99, (5, 5), (1, 1), (2, 2), str(1))
+    pool2 = group(pool1, 99, 198, (3, 3), (1, 1), (1, 1), str(2), 1)
+    pool3 = group(pool2, 198, 387, (3, 3), (1, 1), (1, 1), str(3), 2)
+    pool4 = group(pool3, 387, 261, (3, 3), (1, 1), (1, 1), str(4), 3)
+    pool5 = group(pool4, 261, 261, (3, 3), (1, 1), (1, 1), str(5), 4)
+    fc1 = G.FullyConnected(pool5, fc_hidden, name="fc1")
+    feat = G.MFM(fc1, 3, G.ORDER_RES, name="concat29")  # the node final_efm.py:208 pulls out as 'concat29_output'
+    return feat, fc1
+
+
+def multi_gpu(data, classes):
+    """Returns (id-head output, fc1) like the reference (efm_symbol.py:81-110); the id head is
+    Dropout(0.7) -> FullyConnected(classes) -> softmax and is only materialised when it is asked for."""
+    feat, fc1 = efm_feature(data)
+    fc1.feature = feat
+    fc2 = G.FullyConnected(feat, classes, name="fc2")  # dropout is applied by the id-head wrapper in training
+    return fc2, fc1
+
+
+def get_net(classes, margin=0.2):
+    """Two-output network [id logits, 342-d feature] (ref: efm_symbol.py:112-123, intended behaviour:
+    the reference's MakeLoss(<class>) line is unusable and is not reproduced)."""
+    data = G.Variable("data")
+    logits, fc1 = multi_gpu(data, classes)
+    return [logits, fc1.feature]
+
+
+def embedding_net(embed_dim=128, normalize=True, fc_hidden=513):
+    """BASELINE config 2: EFM-29 -> per-row L2 norm -> Dense(embed_dim, use_bias=False)
+    (ref: final_efm.py:240-243 + pre-trained_efm_v3.py:180-181).  Returns [embedding, feature]."""
+    data = G.Variable("data")
+    feat, _ = efm_feature(data, fc_hidden)
+    x = G.L2Normalization(feat, name="l2norm") if normalize else feat
+    emb = G.FullyConnected(x, embed_dim, name="head", no_bias=True)
+    return [emb, feat]

@@ -101,7 +101,7 @@ def conv_bwd_data(d, dy, wd, add=None, out=None):
     return out
 
 
-def conv_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True):
+def conv_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=False):
     _need_dev(x, dy, dw, dbias)
     if dw is None:
         dw = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=x.device)
@@ -113,7 +113,7 @@ def conv_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True):
     lib = _lib.load()
     nbytes = lib.efm_conv_wgrad_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, x.device)
-    check(lib.efm_conv_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), _p(ws),
+    check(lib.efm_conv_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), int(bool(accumulate)), _p(ws),
                                   ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_conv_bwd_weight")
     return dw, (dbias if want_bias else None)
 
@@ -230,14 +230,21 @@ def triplet_fwd(a, p, n, margin):
     return loss
 
 
-def triplet_bwd(a, p, n, loss, gloss, need_dn=False):
-    _need_rows(a, p, n)
+def triplet_bwd(a, p, n, loss, gloss, need_dn=False, da=None, dp=None, dn=None):
+    """Gradients of the loss vector w.r.t. anchor / positive (/ negative).  `da`, `dp`, `dn` may be preallocated
+    row blocks (unit inner stride, identical row stride) — e.g. the two halves of one (B, D) buffer."""
+    _need_rows(a, p, n, da, dp, dn)
     rows, d = a.shape
-    da = torch.empty((rows, d), dtype=torch.float32, device=a.device)
-    dp = torch.empty_like(da)
-    dn = torch.empty_like(da) if need_dn else None
+    if da is None:
+        da = torch.empty((rows, d), dtype=torch.float32, device=a.device)
+    if dp is None:
+        dp = torch.empty((rows, d), dtype=torch.float32, device=a.device)
+    if dn is None and need_dn:
+        dn = torch.empty((rows, d), dtype=torch.float32, device=a.device)
+    ldg = _ld(da)
+    assert _ld(dp) == ldg and (dn is None or _ld(dn) == ldg)
     check(_lib.load().efm_triplet_bwd(_p(a), _p(p), _p(n), _p(loss), _p(gloss), _p(da), _p(dp), _p(dn), rows, d,
-                                      _ld(a), _ld(p), _ld(n), d, _stream()), "efm_triplet_bwd")
+                                      _ld(a), _ld(p), _ld(n), ldg, _stream()), "efm_triplet_bwd")
     return da, dp, dn
 
 

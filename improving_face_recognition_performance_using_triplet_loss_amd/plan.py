@@ -1,0 +1,327 @@
+"""Static execution plan: lowers a `graph.Sym` DAG onto the HIP kernels and runs it forward and backward.
+
+This plays the role MXNet's executor (`Module.bind` / Gluon `hybridize`, ref: mutli_gpu_v3.py:153-154,
+train_efm.py:209) plays for the reference, designed for one MI355X per process:
+
+  * all parameters live in ONE flat fp32 buffer in the kernels' packed layout (OHWI, padded; see
+    include/efm_hip.h) — the optimiser is a single fused launch over it and the data-parallel gradient
+    exchange is a handful of large RCCL all-reduces over slices of the matching flat gradient buffer;
+  * activations are NHWC with channels padded to 4; a conv's bias and a residual add ride in its epilogue;
+  * backward is a hand-ordered reverse sweep that calls `ready_cb(lo, hi)` as soon as a slice of the flat
+    gradient is final, so the all-reduce of late layers overlaps the backward of early ones.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import graph, ops
+from ._lib import pad4
+
+
+class ParamSpec:
+    __slots__ = ("name", "kind", "offset", "numel", "desc", "mx_shape", "step")
+
+    def __init__(self, name, kind, offset, numel, desc, mx_shape, step):
+        self.name, self.kind, self.offset, self.numel = name, kind, offset, numel
+        self.desc, self.mx_shape, self.step = desc, mx_shape, step
+
+
+class Step:
+    """One lowered operation."""
+
+    def __init__(self, op, node, inputs, shape):
+        self.op = op
+        self.node = node
+        self.inputs = inputs        # producer steps
+        self.shape = shape          # (C, H, W) of the output
+        self.residual = None        # conv only: step whose output is added in the epilogue
+        self.desc = None
+        self.pname = None
+        self.no_bias = False
+        self.needs_grad = False     # does any gradient have to flow into this step's output?
+        self.index = -1
+
+
+class Plan:
+    def __init__(self, outputs, input_shape, device="cuda"):
+        self.device = torch.device(device)
+        self.batch = int(input_shape[0])
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.steps = []
+        self.params = collections.OrderedDict()
+        self._lower(outputs)
+        self._acts = None
+        self._views = {}
+        self._wd_scratch = None
+
+    # ------------------------------------------------------------------------------ lowering
+    def _lower(self, outputs):
+        nodes = graph.topo_sort(outputs)
+        consumers = collections.Counter()
+        for n in nodes:
+            for i in n.inputs:
+                consumers[i.id] += 1
+        for o in outputs:
+            consumers[o.id] += 1
+        step_of = {}
+        b = self.batch
+        offset = 0
+        use_count = collections.Counter()
+        for n in nodes:
+            if n.op == "var":
+                c, h, w = self.input_shape[1:]
+                st = Step("input", n, [], (c, h, w))
+            elif n.op in ("conv", "fc"):
+                src = step_of[n.inputs[0].id]
+                c, h, w = src.shape
+                if n.op == "conv":
+                    (kh, kw), (ph, pw), cout = n.attrs["kernel"], n.attrs["pad"], n.attrs["num_filter"]
+                else:
+                    (kh, kw), (ph, pw), cout = (h, w), (0, 0), n.attrs["num_hidden"]
+                d = ops.conv_desc(b, h, w, c, cout, kh, kw, ph, pw)
+                st = Step("conv", n, [src], (cout, d.hout, d.wout))
+                st.desc, st.pname, st.no_bias = d, n.name, n.attrs["no_bias"]
+                wname = n.name + "_weight"
+                if wname in self.params:  # weight sharing (ref: lightcnn.py:47-48 reused in the loop 52-69)
+                    prev = self.params[wname]
+                    if prev.mx_shape != (cout, c, kh, kw):
+                        raise ValueError("shared parameter %s used with different shapes" % wname)
+                else:
+                    nw = d.n_pad16 * d.k_pad
+                    self.params[wname] = ParamSpec(wname, "weight", offset, nw, d, (cout, c, kh, kw), st)
+                    offset += nw
+                    if not st.no_bias:
+                        self.params[n.name + "_bias"] = ParamSpec(n.name + "_bias", "bias", offset, d.n_pad16, d, (cout,), st)
+                        offset += d.n_pad16
+                use_count[wname] += 1
+            elif n.op == "mfm":
+                src = step_of[n.inputs[0].id]
+                c, h, w = src.shape
+                ways = n.attrs["ways"]
+                if c % ways:
+                    raise ValueError("MFM%d on %d channels" % (ways, c))
+                st = Step("mfm", n, [src], (ops.mfm_out_channels(c, ways), h, w))
+            elif n.op == "pool":
+                src = step_of[n.inputs[0].id]
+                c, h, w = src.shape
+                st = Step("pool", n, [src], (c, h // 2, w // 2))
+            elif n.op == "l2norm":
+                src = step_of[n.inputs[0].id]
+                if src.shape[1:] != (1, 1):
+                    raise ValueError("l2norm expects a (B, C) feature")
+                st = Step("l2norm", n, [src], src.shape)
+            elif n.op == "add":
+                a, bb = step_of[n.inputs[0].id], step_of[n.inputs[1].id]
+                # fuse into the epilogue of whichever side is a single-consumer conv
+                conv, other = None, None
+                for cand, oth, node_in in ((bb, a, n.inputs[1]), (a, bb, n.inputs[0])):
+                    if cand.op == "conv" and cand.residual is None and consumers[node_in.id] == 1:
+                        conv, other = cand, oth
+                        break
+                if conv is None:
+                    raise NotImplementedError("add is only supported as the residual of a single-consumer convolution")
+                if conv.shape != other.shape:
+                    raise ValueError("residual add of mismatching shapes %s vs %s" % (conv.shape, other.shape))
+                conv.residual = other
+                step_of[n.id] = conv
+                continue
+            else:
+                raise NotImplementedError("op %s" % n.op)
+            st.index = len(self.steps)
+            self.steps.append(st)
+            step_of[n.id] = st
+        self.outputs = [step_of[o.id] for o in outputs]
+        self.num_flat = offset
+        self._use_count = dict(use_count)
+        # gradient need: everything downstream of a parameterised step; the raw input needs none
+        for st in self.steps:
+            if st.op == "input":
+                st.needs_grad = False
+            elif st.op == "conv":
+                st.needs_grad = True
+            else:
+                st.needs_grad = any(i.needs_grad for i in st.inputs)
+        self.max_dgrad_elems = max([s.desc.dn_pad16 * s.desc.dk_pad for s in self.steps
+                                    if s.op == "conv" and s.inputs[0].needs_grad] or [0])
+        # a residual source whose only other path needs a gradient
+        self.flops_fwd = sum(2 * s.desc.batch * s.desc.hout * s.desc.wout * s.desc.cout * s.desc.cin * s.desc.kh * s.desc.kw
+                             for s in self.steps if s.op == "conv")
+
+    # --------------------------------------------------------------------------- parameters
+    def new_flat(self):
+        return torch.zeros(self.num_flat, dtype=torch.float32, device=self.device)
+
+    def views(self, flat):
+        """name -> view of `flat` in packed shape (cached per buffer)."""
+        key = (flat.data_ptr(), flat.numel())
+        v = self._views.get(key)
+        if v is None:
+            v = {}
+            for name, ps in self.params.items():
+                t = flat.narrow(0, ps.offset, ps.numel)
+                v[name] = t.view(ps.desc.n_pad16, ps.desc.k_pad) if ps.kind == "weight" else t
+            if len(self._views) > 8:
+                self._views.clear()
+            self._views[key] = v
+        return v
+
+    def load_params(self, flat, params):
+        """params: name -> array in MXNet layout ((Cout,Cin,KH,KW) / (N, C*H*W) for fc / (Cout,))."""
+        v = self.views(flat)
+        for name, ps in self.params.items():
+            if name not in params:
+                raise KeyError("missing parameter %s" % name)
+            a = torch.as_tensor(np.asarray(params[name]), dtype=torch.float32).to(self.device)
+            if ps.kind == "weight":
+                a = a.reshape(ps.mx_shape).contiguous()
+                ops.conv_pack_weights_into(ps.desc, a, v[name])
+            else:
+                v[name].zero_()
+                v[name][: ps.mx_shape[0]].copy_(a.reshape(-1))
+
+    def export_params(self, flat):
+        """-> name -> torch tensor in MXNet layout (fc weights as (N, C*H*W))."""
+        v = self.views(flat)
+        out = collections.OrderedDict()
+        for name, ps in self.params.items():
+            if ps.kind == "weight":
+                w = ops.conv_unpack_weights(ps.desc, v[name])
+                if ps.step.node.op == "fc":
+                    w = w.reshape(ps.mx_shape[0], -1)
+                out[name] = w
+            else:
+                out[name] = v[name][: ps.mx_shape[0]].clone()
+        return out
+
+    def init_xavier(self, flat, seed=42, magnitude=3.0, factor_type="avg"):
+        """Gluon init.Xavier(): uniform(+-sqrt(magnitude / factor)), factor = (fan_in+fan_out)/2 | fan_in | fan_out;
+        biases zero (ref: train_efm.py:208; mutli_gpu_v3.py:156 uses factor_type='in', magnitude=2.34)."""
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        v = self.views(flat)
+        flat.zero_()
+        for name, ps in self.params.items():
+            if ps.kind != "weight":
+                continue
+            cout, cin, kh, kw = ps.mx_shape
+            fan_in, fan_out = cin * kh * kw, cout * kh * kw
+            factor = {"avg": (fan_in + fan_out) / 2.0, "in": fan_in, "out": fan_out}[factor_type]
+            scale = float(np.sqrt(magnitude / factor))
+            w = (torch.rand(ps.mx_shape, generator=gen, device=self.device, dtype=torch.float32) * 2 - 1) * scale
+            ops.conv_pack_weights_into(ps.desc, w, v[name])
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, x, flat, train=True):
+        """x: (B, C, H, W) fp32 device tensor (NCHW, as ImageRecordIter emits).  Returns the output buffers:
+        contiguous (B, pad4(C)) tensors for vector outputs (pads zero), NHWC tensors otherwise."""
+        if tuple(x.shape) != self.input_shape:
+            raise ValueError("plan was compiled for input %s, got %s" % (self.input_shape, tuple(x.shape)))
+        v = self.views(flat)
+        acts = {}
+        aux = {}
+        for st in self.steps:
+            if st.op == "input":
+                acts[st.index] = ops.nchw_to_nhwc(x.contiguous())
+            elif st.op == "conv":
+                w = v[st.pname + "_weight"]
+                bias = None if st.no_bias else v[st.pname + "_bias"]
+                res = acts[st.residual.index] if st.residual is not None else None
+                acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
+            elif st.op == "mfm":
+                acts[st.index] = ops.mfm_fwd(acts[st.inputs[0].index], st.inputs[0].shape[0], st.node.attrs["ways"])
+            elif st.op == "pool":
+                acts[st.index] = ops.maxpool2_fwd(acts[st.inputs[0].index], st.shape[0])
+            elif st.op == "l2norm":
+                src = acts[st.inputs[0].index]
+                c = st.shape[0]
+                cp = pad4(c)
+                y = torch.zeros((self.batch, 1, 1, cp), dtype=torch.float32, device=self.device) if cp != c else \
+                    torch.empty((self.batch, 1, 1, cp), dtype=torch.float32, device=self.device)
+                norm = torch.empty((self.batch,), dtype=torch.float32, device=self.device)
+                ops.check(ops._lib.load().efm_l2norm_fwd(ops._p(src), ops._p(y), ops._p(norm), self.batch, c, cp, cp, 0,
+                                                         ops._stream()), "efm_l2norm_fwd")
+                acts[st.index] = y
+                aux[st.index] = norm
+        self._acts, self._aux = (acts, aux) if train else (None, None)
+        outs = []
+        for st in self.outputs:
+            t = acts[st.index]
+            outs.append(t.view(self.batch, -1) if st.shape[1:] == (1, 1) else t)
+        return outs
+
+    # ----------------------------------------------------------------------------- backward
+    def backward(self, out_grads, flat, grad_flat, ready_cb=None, need_input_grad=False):
+        """out_grads: one tensor per plan output, same padded shape as forward() returned (pads must be zero),
+        or None.  Writes d(loss)/d(params) into `grad_flat` (overwrite; shared parameters accumulate within the
+        sweep).  Returns the NHWC input gradient when `need_input_grad`."""
+        if self._acts is None:
+            raise RuntimeError("backward() needs a forward(train=True) first")
+        acts, aux = self._acts, self._aux
+        v, gv = self.views(flat), self.views(grad_flat)
+        gr = {}
+        for st, g in zip(self.outputs, out_grads):
+            if g is None:
+                continue
+            g = g.contiguous()
+            if st.index in gr:
+                raise NotImplementedError("the same step listed twice as an output")
+            gr[st.index] = g
+        written = set()
+        remaining = dict(self._use_count)
+        if self.max_dgrad_elems and (self._wd_scratch is None or self._wd_scratch.numel() < self.max_dgrad_elems):
+            self._wd_scratch = torch.empty(self.max_dgrad_elems, dtype=torch.float32, device=self.device)
+        dx_input = None
+        for st in reversed(self.steps):
+            dy = gr.pop(st.index, None)
+            if dy is None:
+                continue
+            if st.op == "conv":
+                d = st.desc
+                src = st.inputs[0]
+                wname = st.pname + "_weight"
+                acc = wname in written
+                ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
+                                    want_bias=not st.no_bias, accumulate=acc)
+                written.add(wname)
+                if st.residual is not None:
+                    r = st.residual.index
+                    if r in gr:
+                        raise NotImplementedError("two gradient contributions to a residual source before its own backward")
+                    gr[r] = dy  # identity path: alias, consumed (read-only) by the source's other consumer
+                if src.needs_grad or (src.op == "input" and need_input_grad):
+                    wd = self._wd_scratch[: d.dn_pad16 * d.dk_pad]
+                    ops.conv_make_dgrad_weights(d, v[wname], out=wd)
+                    prev = gr.pop(src.index, None)
+                    gr[src.index] = ops.conv_bwd_data(d, dy, wd, add=prev)
+                remaining[wname] -= 1
+                if ready_cb is not None and remaining[wname] == 0:
+                    ps = self.params[wname]
+                    hi = ps.offset + ps.numel + (0 if st.no_bias else d.n_pad16)
+                    ready_cb(ps.offset, hi)
+            elif st.op == "mfm":
+                src = st.inputs[0]
+                prev = gr.pop(src.index, None)
+                gr[src.index] = ops.mfm_bwd(acts[src.index], dy, src.shape[0], st.node.attrs["ways"], st.node.attrs["order"], add=prev)
+            elif st.op == "pool":
+                src = st.inputs[0]
+                if src.index in gr:
+                    raise NotImplementedError("pool input with a second gradient contribution")
+                gr[src.index] = ops.maxpool2_bwd(acts[src.index], dy, src.shape[0])
+            elif st.op == "l2norm":
+                src = st.inputs[0]
+                c = st.shape[0]
+                cp = pad4(c)
+                if src.index in gr:
+                    raise NotImplementedError("l2norm input with a second gradient contribution")
+                dx = torch.zeros((self.batch, 1, 1, cp), dtype=torch.float32, device=self.device) if cp != c else \
+                    torch.empty((self.batch, 1, 1, cp), dtype=torch.float32, device=self.device)
+                ops.check(ops._lib.load().efm_l2norm_bwd(ops._p(acts[st.index]), ops._p(aux[st.index]), ops._p(dy), ops._p(dx),
+                                                         self.batch, c, cp, cp, cp, 0, ops._stream()), "efm_l2norm_bwd")
+                gr[src.index] = dx
+            elif st.op == "input":
+                dx_input = dy
+        return dx_input
+
+    def release(self):
+        self._acts = self._aux = None

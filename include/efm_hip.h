@@ -98,10 +98,12 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
 /* dx = conv_transpose(dy, w) (+ add).  `add` has dx's shape or NULL (skip-path gradient). */
 int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed,
                       const float* add, float* dx, void* stream);
-/* dw_packed[n][k] = sum_m dy[m][n] * im2col(x)[m][k]; dbias[n] = sum_m dy[m][n] (dbias may be NULL).
- * Deterministic: split over m into workspace slabs, then a fixed-order reduction. */
+/* dw_packed[n][k] (+)= sum_m dy[m][n] * im2col(x)[m][k]; dbias[n] (+)= sum_m dy[m][n] (dbias may be NULL).
+ * accumulate != 0 adds to the existing contents (weight sharing: the Gluon res_block re-applies the same two
+ * convolutions, ref: lightcnn.py:47-48,52-69).  Deterministic: split over m into workspace slabs, then a
+ * fixed-order reduction. */
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed,
-                        float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+                        float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).

@@ -1,0 +1,142 @@
+"""End-to-end GPU parity of the EFM-29 embedding path (plan + trainer) against the CPU oracles.
+
+Tolerance is the north star's: 1e-3 relative fp32 (measured here as max|diff| / max|ref|) for embeddings, loss
+and every parameter gradient.  Inputs / weights come from the portable splitmix64 generator, nothing is read
+from /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import efm_oracle as O
+from oracle import efm_oracle_torch as OT
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _make(batch, image, seed=1234):
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    shapes = O.efm29_param_shapes(3, image)
+    params = O.init_params(shapes, 42)
+    w_head = O.uniform_pm((128, 342), 777, O.xavier_uniform_scale((128, 342)))
+    x = O.uniform01(batch * 3 * image * image, seed).reshape(batch, 3, image, image)
+    tr = TripletTrainer(batch, image=image, optimizer="sgd", lr=0.05, wd=1e-5)
+    allp = dict(params)
+    allp["head_weight"] = w_head
+    tr.plan.load_params(tr.flat, allp)
+    return tr, params, w_head, x
+
+
+def test_param_table_matches_reference_names():
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    tr = TripletTrainer(2, image=112)
+    shapes = O.efm29_param_shapes(3, 112)
+    mine = {n: tuple(ps.mx_shape) for n, ps in tr.plan.params.items() if n != "head_weight"}
+    ref = {n: (s if not n == "fc1_weight" else (513, 174, 3, 3)) for n, s in shapes.items()}
+    assert mine == ref
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 9068013
+    # pack/export round trip is exact
+    exp = tr.plan.export_params(tr.flat)
+    flat2 = tr.plan.new_flat()
+    tr.plan.load_params(flat2, {k: v.cpu().numpy() for k, v in exp.items()})
+    assert torch.equal(flat2, tr.flat)
+
+
+def test_mini_efm_step_vs_numpy_oracle():
+    """B=4 (2 anchors + 2 positives), 3x32x32, all 29 convs real width (SURVEY.md §8c fixture (ii))."""
+    tr, params, w_head, x = _make(4, 32)
+    neg = np.array([1, 0], dtype=np.int32)
+    loss_r, emb_r, feat_r, grads_r, ghead_r = O.train_step_loss(params, w_head, x, neg, 0.2)
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), torch.as_tensor(neg).cuda())
+    assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r) < TOL
+    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r) < TOL
+    assert rel_err(loss.cpu().numpy(), loss_r) < TOL
+    tr.backward()
+    g = tr.plan.export_params(tr.grad)
+    worst = 0.0
+    for name, ref in grads_r.items():
+        got = g[name].cpu().numpy().reshape(ref.shape)
+        worst = max(worst, rel_err(got, ref))
+    assert worst < TOL, worst
+    assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), ghead_r) < TOL
+    # SGD update against the oracle formula, rescale = 1/(B/2)
+    before = tr.plan.export_params(tr.flat)["conv3_res_weight"].cpu().numpy().astype(np.float64)
+    tr.update()
+    after = tr.plan.export_params(tr.flat)["conv3_res_weight"].cpu().numpy()
+    assert rel_err(after, O.sgd_step(before, grads_r["conv3_res_weight"], 0.05, 1e-5, 0.5)) < 1e-5
+    # cosine log rows
+    s_ap, s_an = tr.cosine_log()
+    r_ap, r_an = O.cosine_dist(emb_r[:2], emb_r[2:], emb_r[neg])
+    assert rel_err(s_ap.cpu().numpy(), r_ap) < TOL and rel_err(s_an.cpu().numpy(), r_an) < TOL
+
+
+def test_112_step_vs_torch_oracle():
+    """3x112x112 (the BASELINE geometry, 7->3 floor pooling included), B=8, torch-CPU fp64 oracle."""
+    tr, params, w_head, x = _make(8, 112)
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    labels = synth.parity_labels(8, images_per_identity=2)
+    neg = synth.negative_indices(labels, 99)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    twh = torch.tensor(w_head, dtype=torch.float64, requires_grad=True)
+    loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x), neg.long(), 0.2)
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg.cuda())
+    assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r.numpy()) < TOL
+    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r.numpy()) < TOL
+    assert rel_err(loss.cpu().numpy(), loss_r.numpy()) < TOL
+    tr.backward()
+    g = tr.plan.export_params(tr.grad)
+    worst, worst_name = 0.0, None
+    for name, t in tp.items():
+        ref = t.grad.numpy()
+        e = rel_err(g[name].cpu().numpy().reshape(ref.shape), ref)
+        if e > worst:
+            worst, worst_name = e, name
+    assert worst < TOL, (worst, worst_name)
+    assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), twh.grad.numpy()) < TOL
+
+
+def test_step_is_bitwise_reproducible():
+    """No atomics anywhere: two runs of the same step give identical bits (SURVEY.md §7 'hard parts')."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    outs = []
+    for _ in range(2):
+        tr = TripletTrainer(16, image=64, seed=3)
+        x = synth.images(16, 3, 64, 11)
+        labels = synth.parity_labels(16, images_per_identity=2)
+        neg = synth.negative_indices(labels, 5).cuda()
+        tr.step(x, neg)
+        outs.append((tr.grad.clone(), tr.flat.clone(), tr.last["loss"].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_shard_sum_identity():
+    """Data parallelism by construction: the sum of the gradients of two half-batches (each with its own local
+    negatives) equals the gradient of one process that runs both halves — the all-reduce is a plain SUM and the
+    1/global_batch scale lives in the optimiser (ref: mutli_gpu_v3.py:159)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    shard_grads = []
+    for rank in range(2):
+        tr = TripletTrainer(8, image=32, seed=3)
+        x = synth.images(8, 3, 32, 100 + rank)
+        neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).cuda()
+        tr.forward_loss(x, neg)
+        tr.backward()
+        shard_grads.append(tr.plan.export_params(tr.grad))
+    # the same two shards through the fp64 oracle, summed
+    tr = TripletTrainer(8, image=32, seed=3)
+    params = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.export_params(tr.flat).items()}
+    w_head = params.pop("head_weight").reshape(128, 342)
+    params["fc1_weight"] = params["fc1_weight"].reshape(513, -1)
+    total = None
+    for rank in range(2):
+        x = synth.images(8, 3, 32, 100 + rank).cpu().numpy().astype(np.float64)
+        neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).numpy()
+        _, _, _, grads, _ = O.train_step_loss(params, w_head, x, neg, 0.2)
+        total = grads if total is None else {k: total[k] + grads[k] for k in grads}
+    for name in ("conv1_weight", "conv3_res_weight", "conv5_weight", "fc1_weight"):
+        got = (shard_grads[0][name] + shard_grads[1][name]).cpu().numpy()
+        assert rel_err(got.reshape(total[name].shape), total[name]) < TOL, name
