@@ -50,11 +50,13 @@ class TripletTrainer:
         self.last = {"emb": emb, "feat": feat, "a": a, "p": p, "n": n, "loss": loss}
         return loss
 
-    def backward(self):
+    def backward(self, demb=None):
+        """`demb` (B, D) overrides the loss's own upstream gradient (used by the parity tests as a well-conditioned probe)."""
         L = self.last
-        demb = torch.zeros_like(L["emb"])
-        # vector backward = ones head-gradient (Gluon loss.backward()); the 1/B mean is the optimiser's rescale
-        ops.triplet_bwd(L["a"], L["p"], L["n"], L["loss"], self._ones, da=demb[: self.half], dp=demb[self.half:])
+        if demb is None:
+            demb = torch.zeros_like(L["emb"])
+            # vector backward = ones head-gradient (Gluon loss.backward()); the 1/B mean is the optimiser's rescale
+            ops.triplet_bwd(L["a"], L["p"], L["n"], L["loss"], self._ones, da=demb[: self.half], dp=demb[self.half:])
         self.plan.backward([demb, None], self.flat, self.grad, ready_cb=self.reducer.ready)
         self.reducer.finish()
 

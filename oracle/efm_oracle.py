@@ -433,10 +433,12 @@ def head_forward(w_head, feat, normalize="row"):
     return y @ w_head.T, (y, n)
 
 
-def train_step_loss(params, w_head, x, neg_idx, margin, in_channels=3):
+def train_step_loss(params, w_head, x, neg_idx, margin, in_channels=3, demb=None):
     """One reference-layout step: batch = [B/2 anchors ; B/2 positives], negatives = detached rows of the anchor
     half picked by `neg_idx` (ref: train_efm.py:232-241), loss vector (B/2,), head on row-normalised features.
-    Returns (loss, emb, feat, grads, g_head)."""
+    Returns (loss, emb, feat, grads, g_head).  With `demb` given, that upstream gradient replaces the loss's own
+    (a well-conditioned probe of the backward pass: at random init all embeddings nearly coincide, so the loss
+    gradient 2(n-p) is a difference of nearly equal fp32 numbers)."""
     tape = Tape()
     feat, acts = efm29_forward(params, x, tape, in_channels)
     emb, (yn, nrm) = head_forward(w_head, feat)
@@ -444,8 +446,9 @@ def train_step_loss(params, w_head, x, neg_idx, margin, in_channels=3):
     a, p = emb[:h], emb[h:]
     n = emb[neg_idx]
     loss = triplet_loss(a, p, n, margin)
-    da, dp, _ = triplet_loss_bwd(a, p, n, loss, np.ones_like(loss))  # vector backward = ones head-grad [MX-assumed (9)]
-    demb = np.concatenate([da, dp], axis=0)
+    if demb is None:
+        da, dp, _ = triplet_loss_bwd(a, p, n, loss, np.ones_like(loss))  # vector backward = ones head-grad [MX-assumed (9)]
+        demb = np.concatenate([da, dp], axis=0)
     g_head = demb.T @ yn
     dyn = demb @ w_head
     dfeat = l2norm_row_bwd(yn, nrm, dyn)

@@ -53,9 +53,9 @@ def triplet_loss(a, p, n, margin):
     return F.relu(((p - a) ** 2 - (n - a) ** 2).sum(dim=1) + margin)
 
 
-def train_step(p, w_head, x, neg_idx, margin):
+def train_step(p, w_head, x, neg_idx, margin, demb=None):
     """Reference-layout step (see efm_oracle.train_step_loss): returns (loss vector, emb, feat); gradients land in
-    .grad of every tensor of `p` and of `w_head`."""
+    .grad of every tensor of `p` and of `w_head`.  `demb` (optional) replaces the loss's own upstream gradient."""
     feat = efm29_forward(p, x)
     yn = feat / feat.norm(dim=1, keepdim=True)
     emb = yn @ w_head.t()
@@ -63,5 +63,8 @@ def train_step(p, w_head, x, neg_idx, margin):
     a, pos = emb[:h], emb[h:]
     n = emb[neg_idx].detach()  # negatives are copied through NumPy in the reference (train_efm.py:238-239)
     loss = triplet_loss(a, pos, n, margin)
-    loss.sum().backward()  # vector backward = ones head-gradient
+    if demb is None:
+        loss.sum().backward()  # vector backward = ones head-gradient
+    else:
+        emb.backward(demb)
     return loss.detach(), emb.detach(), feat.detach()

@@ -48,12 +48,13 @@ def test_mini_efm_step_vs_numpy_oracle():
     """B=4 (2 anchors + 2 positives), 3x32x32, all 29 convs real width (SURVEY.md §8c fixture (ii))."""
     tr, params, w_head, x = _make(4, 32)
     neg = np.array([1, 0], dtype=np.int32)
-    loss_r, emb_r, feat_r, grads_r, ghead_r = O.train_step_loss(params, w_head, x, neg, 0.2)
+    demb = np.random.default_rng(5).uniform(-1, 1, size=(4, 128))
+    loss_r, emb_r, feat_r, grads_r, ghead_r = O.train_step_loss(params, w_head, x, neg, 0.2, demb=demb)
     loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), torch.as_tensor(neg).cuda())
     assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r) < TOL
     assert rel_err(tr.last["emb"].cpu().numpy(), emb_r) < TOL
     assert rel_err(loss.cpu().numpy(), loss_r) < TOL
-    tr.backward()
+    tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
     g = tr.plan.export_params(tr.grad)
     worst = 0.0
     for name, ref in grads_r.items():
@@ -61,6 +62,12 @@ def test_mini_efm_step_vs_numpy_oracle():
         worst = max(worst, rel_err(got, ref))
     assert worst < TOL, worst
     assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), ghead_r) < TOL
+    # the loss's own gradient (difference of nearly equal embeddings: conditioning-limited, see oracle docstring)
+    _, _, _, grads_l, _ = O.train_step_loss(params, w_head, x, neg, 0.2)
+    tr.backward()
+    gl = tr.plan.export_params(tr.grad)
+    assert rel_err(gl["conv3_res_weight"].cpu().numpy(), grads_l["conv3_res_weight"]) < 5e-2
+    tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
     # SGD update against the oracle formula, rescale = 1/(B/2)
     before = tr.plan.export_params(tr.flat)["conv3_res_weight"].cpu().numpy().astype(np.float64)
     tr.update()
@@ -80,12 +87,13 @@ def test_112_step_vs_torch_oracle():
     neg = synth.negative_indices(labels, 99)
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
     twh = torch.tensor(w_head, dtype=torch.float64, requires_grad=True)
-    loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x), neg.long(), 0.2)
+    demb = torch.as_tensor(np.random.default_rng(6).uniform(-1, 1, size=(8, 128)))
+    loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x), neg.long(), 0.2, demb=demb)
     loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg.cuda())
     assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r.numpy()) < TOL
     assert rel_err(tr.last["emb"].cpu().numpy(), emb_r.numpy()) < TOL
     assert rel_err(loss.cpu().numpy(), loss_r.numpy()) < TOL
-    tr.backward()
+    tr.backward(demb=demb.float().cuda())
     g = tr.plan.export_params(tr.grad)
     worst, worst_name = 0.0, None
     for name, t in tp.items():
@@ -119,12 +127,13 @@ def test_shard_sum_identity():
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
     shard_grads = []
+    DEMB = [np.random.default_rng(40 + r).uniform(-1, 1, size=(8, 128)) for r in range(2)]
     for rank in range(2):
         tr = TripletTrainer(8, image=32, seed=3)
         x = synth.images(8, 3, 32, 100 + rank)
         neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).cuda()
         tr.forward_loss(x, neg)
-        tr.backward()
+        tr.backward(demb=torch.as_tensor(DEMB[rank], dtype=torch.float32).cuda())
         shard_grads.append(tr.plan.export_params(tr.grad))
     # the same two shards through the fp64 oracle, summed
     tr = TripletTrainer(8, image=32, seed=3)
@@ -135,7 +144,7 @@ def test_shard_sum_identity():
     for rank in range(2):
         x = synth.images(8, 3, 32, 100 + rank).cpu().numpy().astype(np.float64)
         neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).numpy()
-        _, _, _, grads, _ = O.train_step_loss(params, w_head, x, neg, 0.2)
+        _, _, _, grads, _ = O.train_step_loss(params, w_head, x, neg, 0.2, demb=DEMB[rank])
         total = grads if total is None else {k: total[k] + grads[k] for k in grads}
     for name in ("conv1_weight", "conv3_res_weight", "conv5_weight", "fc1_weight"):
         got = (shard_grads[0][name] + shard_grads[1][name]).cpu().numpy()
