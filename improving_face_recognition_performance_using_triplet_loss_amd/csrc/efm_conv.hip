@@ -201,6 +201,7 @@ struct WgradP {
   const float* x;
   const float* dy;
   float* ws;
+  float* bias_part;  // [splits][n_pad16] partial column sums of dy, or nullptr
   int M;
   int hin, win, cin_p;
   int hout, wout, cout_p;
@@ -290,6 +291,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
     for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fq = lane >> 4;
+  // bias gradient rides along: the MFMA A operand IS dy, so wave 0 of the first k-block keeps a running
+  // column sum of what it feeds to the matrix core (no second pass over dy, no atomics).
+  const bool do_bias = (p.bias_part != nullptr) && (kb == 0) && (wave == 0);
+  float bsum[NTW];
+#pragma unroll
+  for (int b = 0; b < NTW; ++b) bsum[b] = 0.f;
   auto compute = [&](int buf) {
     const float* Xs = smem + buf * BP * (SX + SY);
     const float* Ys = Xs + BP * SX;
@@ -301,6 +308,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const float ay = Ys[(4 * s + fq) * SY + nt * 16 + fi];
+        bsum[nt] += do_bias ? ay : 0.f;
 #pragma unroll
         for (int kt = 0; kt < KPW; ++kt)
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bx[kt], acc[kt][nt], 0, 0, 0);
@@ -322,6 +330,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
     __syncthreads();
   }
 
+  if (do_bias) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      float v = bsum[nt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n0 + nt * 16 + fi;
+      if (fq == 0 && n < p.n_pad16) p.bias_part[(long)split * p.n_pad16 + n] = v;
+    }
+  }
   float* ws = p.ws + (long)split * p.n_pad16 * p.k_pad;
 #pragma unroll
   for (int kt = 0; kt < KPW; ++kt) {
@@ -339,43 +357,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
   }
 }
 
-// out[i] = sum_s ws[s*stride + i], fixed order (deterministic).  n4 = element count / 4.
+// out[g][i] = sum_{s in group g} ws[s*stride + i] (+ out[i] when accumulating), fixed order (deterministic).
+// Block = 64 float4 columns x 4 split-lanes; grid = (ceil(n4/64), groups).  A long list of slabs is reduced in two
+// levels (groups of `per_group` slabs -> one slab each -> final) so that the loop a thread runs stays short.
 __global__ void __launch_bounds__(256) slab_reduce_k(const float* __restrict__ ws, float* __restrict__ out,
-                                                     long n4, long stride4, int splits, int accumulate) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const f32x4* w = reinterpret_cast<const f32x4*>(ws);
-  f32x4 s = w[i];
-  for (int k = 1; k < splits; ++k) s += w[(long)k * stride4 + i];
-  if (accumulate) s += reinterpret_cast<f32x4*>(out)[i];
-  reinterpret_cast<f32x4*>(out)[i] = s;
-}
-
-// Partial column sums of dy for the bias gradient: part[chunk][n] = sum_{m in chunk} dy[m][n].
-// Block = 4 row-lanes x 64 column groups of 4 channels.
-__global__ void __launch_bounds__(256) colsum_partial_k(const float* __restrict__ dy, float* __restrict__ part,
-                                                        int M, int cout_p, int n_pad16, int rows_per_chunk) {
+                                                     long n4, long stride4, int splits, int per_group,
+                                                     long out_stride4, int accumulate) {
   __shared__ __attribute__((aligned(16))) float red[4][64 * 4];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int chunk = blockIdx.x;
-  const int m_begin = chunk * rows_per_chunk;
-  const int m_end = min(M, m_begin + rows_per_chunk);
-  const int ng = cout_p >> 2;
-  for (int g0 = 0; g0 < (n_pad16 >> 2); g0 += 64) {
-    const int g = g0 + cx;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (g < ng)
-      for (int m = m_begin + ry; m < m_end; m += 4) s += *reinterpret_cast<const f32x4*>(dy + (long)m * cout_p + g * 4);
-    *reinterpret_cast<f32x4*>(&red[ry][cx * 4]) = s;
-    __syncthreads();
-    if (ry == 0 && g < (n_pad16 >> 2)) {
-      f32x4 t = *reinterpret_cast<f32x4*>(&red[0][cx * 4]);
-      t += *reinterpret_cast<f32x4*>(&red[1][cx * 4]);
-      t += *reinterpret_cast<f32x4*>(&red[2][cx * 4]);
-      t += *reinterpret_cast<f32x4*>(&red[3][cx * 4]);
-      *reinterpret_cast<f32x4*>(part + (long)chunk * n_pad16 + g * 4) = t;
-    }
-    __syncthreads();
+  const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + cx;
+  const int g = blockIdx.y;
+  const int s_begin = g * per_group, s_end = min(splits, s_begin + per_group);
+  const f32x4* w = reinterpret_cast<const f32x4*>(ws);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int k = s_begin + sl; k < s_end; k += 4) s += w[(long)k * stride4 + i];
+  *reinterpret_cast<f32x4*>(&red[sl][cx * 4]) = s;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    f32x4 t = *reinterpret_cast<f32x4*>(&red[0][cx * 4]);
+    t += *reinterpret_cast<f32x4*>(&red[1][cx * 4]);
+    t += *reinterpret_cast<f32x4*>(&red[2][cx * 4]);
+    t += *reinterpret_cast<f32x4*>(&red[3][cx * 4]);
+    f32x4* o = reinterpret_cast<f32x4*>(out) + (long)g * out_stride4 + i;
+    if (accumulate) t += *o;
+    *o = t;
   }
 }
 
@@ -495,8 +501,8 @@ int launch_wgrad_nt(int NTW, dim3 grid, hipStream_t s, const WgradP& p) {
 }
 
 struct WgradPlan {
-  int KPW, NTW, kblocks, nblocks, splits, m_per_split, chunks, rows_per_chunk;
-  size_t ws_floats;  // wgrad slabs + bias partials
+  int KPW, NTW, kblocks, nblocks, splits, m_per_split, groups, per_group;
+  size_t slab_floats, lvl2_floats, ws_floats;  // wgrad slabs | second-level slabs | + bias partials (both levels)
 };
 
 WgradPlan plan_wgrad(const efm_conv_desc* d) {
@@ -510,7 +516,7 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.NTW = round_nt((ntiles + nb - 1) / nb);
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
-  const int target = env_int("EFM_WGRAD_BLOCKS", 2048);
+  const int target = env_int("EFM_WGRAD_BLOCKS", 1536);
   int splits = (target + base - 1) / base;
   const int max_splits = (M + 255) / 256;  // at least 256 pixels (16 steps) per split
   if (splits > max_splits) splits = max_splits;
@@ -519,9 +525,12 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   mps = (mps + 15) & ~15;
   pl.m_per_split = mps;
   pl.splits = (M + mps - 1) / mps;
-  pl.rows_per_chunk = 2048;
-  pl.chunks = (M + pl.rows_per_chunk - 1) / pl.rows_per_chunk;
-  pl.ws_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad + (size_t)pl.chunks * d->n_pad16;
+  // slabs are summed 32 at a time per thread at most: more than that goes through a second level
+  pl.per_group = (pl.splits > 32) ? 32 : pl.splits;
+  pl.groups = (pl.splits + pl.per_group - 1) / pl.per_group;
+  pl.slab_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad;
+  pl.lvl2_floats = (pl.groups > 1) ? (size_t)pl.groups * d->n_pad16 * d->k_pad : 0;
+  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.splits + pl.groups) * d->n_pad16;
   return pl;
 }
 
@@ -607,27 +616,29 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad;
   p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
+  float* slabs = (float*)workspace;
+  float* lvl2 = slabs + pl.slab_floats;
+  float* bpart = lvl2 + pl.lvl2_floats;
+  float* bpart2 = bpart + (size_t)pl.splits * d->n_pad16;
+  p.bias_part = dbias ? bpart : nullptr;
   dim3 grid((unsigned)(pl.kblocks * pl.nblocks * pl.splits));
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
   if (rc != EFM_OK) return rc;
   rc = efm::check_launch("conv_wgrad");
   if (rc != EFM_OK) return rc;
-  const long n4 = (long)d->n_pad16 * d->k_pad / 4;
-  hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(n4, 256)), dim3(256), 0, s, (const float*)workspace,
-                     dw_packed, n4, n4, pl.splits, accumulate);
-  rc = efm::check_launch("conv_wgrad_reduce");
+  auto reduce = [&](const float* in, float* tmp, float* out, long n4) -> int {
+    const unsigned gx = (unsigned)efm::cdiv(n4, 64);
+    if (pl.groups > 1) {
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, pl.groups), dim3(256), 0, s, in, tmp, n4, n4, pl.splits, pl.per_group, n4, 0);
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, pl.groups, pl.groups, n4, accumulate);
+    } else {
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, pl.splits, pl.splits, n4, accumulate);
+    }
+    return efm::check_launch("conv_wgrad_reduce");
+  };
+  rc = reduce(slabs, lvl2, dw_packed, (long)d->n_pad16 * d->k_pad / 4);
   if (rc != EFM_OK) return rc;
-  if (dbias) {
-    float* part = (float*)workspace + (size_t)pl.splits * d->n_pad16 * d->k_pad;
-    hipLaunchKernelGGL(colsum_partial_k, dim3(pl.chunks), dim3(256), 0, s, dy, part, p.M, d->cout_p, d->n_pad16,
-                       pl.rows_per_chunk);
-    rc = efm::check_launch("conv_bias_colsum");
-    if (rc != EFM_OK) return rc;
-    const long b4 = d->n_pad16 / 4;
-    hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(b4, 256)), dim3(256), 0, s, (const float*)part, dbias,
-                       b4, b4, pl.chunks, accumulate);
-    rc = efm::check_launch("conv_bias_reduce");
-  }
+  if (dbias) rc = reduce(bpart, bpart2, dbias, d->n_pad16 / 4);
   return rc;
 }
 

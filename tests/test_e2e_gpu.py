@@ -80,29 +80,42 @@ def test_mini_efm_step_vs_numpy_oracle():
 
 
 def test_112_step_vs_torch_oracle():
-    """3x112x112 (the BASELINE geometry, 7->3 floor pooling included), B=8, torch-CPU fp64 oracle."""
+    """3x112x112 (the BASELINE geometry, 7->3 floor pooling included), B=8, torch-CPU fp64 oracle.
+
+    Forward (feature, embedding, loss): 1e-3.  Gradients: max/min/pool route the gradient through arg-max
+    decisions, so a last-bit difference in a forward value can flip a route — a fp32 run of the SAME oracle on the
+    CPU differs from its fp64 run by ~5e-3 here.  The HIP path is therefore held to max(1e-3, 3x that fp32-CPU
+    noise floor), measured in the same test; kernel-level backward parity at 2e-4 is in test_kernels_gpu.py and
+    the flip-free mini network above holds 1e-3 end to end."""
     tr, params, w_head, x = _make(8, 112)
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     labels = synth.parity_labels(8, images_per_identity=2)
     neg = synth.negative_indices(labels, 99)
-    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
-    twh = torch.tensor(w_head, dtype=torch.float64, requires_grad=True)
     demb = torch.as_tensor(np.random.default_rng(6).uniform(-1, 1, size=(8, 128)))
-    loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x), neg.long(), 0.2, demb=demb)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        tp = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in params.items()}
+        twh = torch.tensor(w_head, dtype=dt, requires_grad=True)
+        loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x, dtype=dt), neg.long(), 0.2, demb=demb.to(dt))
+        grads = {k: t.grad.double().numpy() for k, t in tp.items()}
+        grads["head_weight"] = twh.grad.double().numpy()
+        ref[dt] = (loss_r.double().numpy(), emb_r.double().numpy(), feat_r.double().numpy(), grads)
+    loss_r, emb_r, feat_r, grads_r = ref[torch.float64]
     loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg.cuda())
-    assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r.numpy()) < TOL
-    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r.numpy()) < TOL
-    assert rel_err(loss.cpu().numpy(), loss_r.numpy()) < TOL
+    assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r) < TOL
+    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r) < TOL
+    assert rel_err(loss.cpu().numpy(), loss_r) < TOL
     tr.backward(demb=demb.float().cuda())
     g = tr.plan.export_params(tr.grad)
+    floor = max(rel_err(ref[torch.float32][3][k], grads_r[k]) for k in grads_r)
+    bound = max(TOL, 3.0 * floor)
     worst, worst_name = 0.0, None
-    for name, t in tp.items():
-        ref = t.grad.numpy()
-        e = rel_err(g[name].cpu().numpy().reshape(ref.shape), ref)
+    for name, r in grads_r.items():
+        e = rel_err(g[name].cpu().numpy().reshape(r.shape), r)
         if e > worst:
             worst, worst_name = e, name
-    assert worst < TOL, (worst, worst_name)
-    assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), twh.grad.numpy()) < TOL
+    print("112 gradient parity: worst %.3e (%s), fp32-CPU noise floor %.3e" % (worst, worst_name, floor))
+    assert worst < bound, (worst, worst_name, floor)
 
 
 def test_step_is_bitwise_reproducible():
@@ -121,31 +134,29 @@ def test_step_is_bitwise_reproducible():
 
 
 def test_shard_sum_identity():
-    """Data parallelism by construction: the sum of the gradients of two half-batches (each with its own local
-    negatives) equals the gradient of one process that runs both halves — the all-reduce is a plain SUM and the
-    1/global_batch scale lives in the optimiser (ref: mutli_gpu_v3.py:159)."""
+    """Data parallelism by construction: two ranks with 8 images each (own anchors, positives and LOCAL negatives,
+    ref: train_efm.py:234-239) produce gradients whose SUM equals the gradient of one process that runs the same 16
+    images with the same triplets — the all-reduce is a plain sum and the 1/global_batch scale lives in the optimiser
+    (ref: mutli_gpu_v3.py:159).  Forward values are per-sample and bitwise independent of the batch they sit in, so
+    the arg-max routes agree and only the split-K summation order differs: tolerance 1e-4."""
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
-    shard_grads = []
-    DEMB = [np.random.default_rng(40 + r).uniform(-1, 1, size=(8, 128)) for r in range(2)]
+    xs, negs, shard_grads, shard_loss = [], [], [], []
     for rank in range(2):
         tr = TripletTrainer(8, image=32, seed=3)
         x = synth.images(8, 3, 32, 100 + rank)
         neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).cuda()
-        tr.forward_loss(x, neg)
-        tr.backward(demb=torch.as_tensor(DEMB[rank], dtype=torch.float32).cuda())
-        shard_grads.append(tr.plan.export_params(tr.grad))
-    # the same two shards through the fp64 oracle, summed
-    tr = TripletTrainer(8, image=32, seed=3)
-    params = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.export_params(tr.flat).items()}
-    w_head = params.pop("head_weight").reshape(128, 342)
-    params["fc1_weight"] = params["fc1_weight"].reshape(513, -1)
-    total = None
-    for rank in range(2):
-        x = synth.images(8, 3, 32, 100 + rank).cpu().numpy().astype(np.float64)
-        neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 5 + rank).numpy()
-        _, _, _, grads, _ = O.train_step_loss(params, w_head, x, neg, 0.2, demb=DEMB[rank])
-        total = grads if total is None else {k: total[k] + grads[k] for k in grads}
-    for name in ("conv1_weight", "conv3_res_weight", "conv5_weight", "fc1_weight"):
-        got = (shard_grads[0][name] + shard_grads[1][name]).cpu().numpy()
-        assert rel_err(got.reshape(total[name].shape), total[name]) < TOL, name
+        shard_loss.append(tr.forward_loss(x, neg).clone())
+        tr.backward()
+        shard_grads.append(tr.grad.clone())
+        xs.append(x)
+        negs.append(neg)
+    big = TripletTrainer(16, image=32, seed=3)
+    x = torch.cat([xs[0][:4], xs[1][:4], xs[0][4:], xs[1][4:]])          # [anchors r0, anchors r1 ; positives r0, r1]
+    neg = torch.cat([negs[0], negs[1] + 4]).to(torch.int32)
+    loss = big.forward_loss(x, neg)
+    big.backward()
+    assert torch.equal(loss, torch.cat(shard_loss))                       # per-sample forward is batch independent
+    total = shard_grads[0] + shard_grads[1]
+    err = float((total - big.grad).abs().max() / big.grad.abs().max())
+    assert err < 1e-4, err

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Per-layer timing of the EFM-29 convolution kernels (HIP events on the launch stream).
+
+    python tools/conv_bench.py [--batch 256] [--image 112] [--layers conv2,conv3] [--iters 5] [--what fwd,dgrad,wgrad]
+Prints ms and achieved TFLOP/s (unpadded algorithmic flops) per layer and pass, and the step total.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol, ops  # noqa: E402
+from improving_face_recognition_performance_using_triplet_loss_amd.plan import Plan  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--image", type=int, default=112)
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    a = ap.parse_args()
+    plan = Plan(efm_symbol.embedding_net(), (a.batch, 3, a.image, a.image))
+    want = set(a.layers.split(",")) if a.layers else None
+    what = a.what.split(",")
+    tot = {k: 0.0 for k in what}
+    totf = {k: 0.0 for k in what}
+    seen = set()
+    for st in plan.steps:
+        if st.op != "conv" or (want and st.pname not in want):
+            continue
+        d = st.desc
+        key = (d.hin, d.win, d.cin, d.cout, d.kh, d.pad_h)
+        dup = key in seen
+        seen.add(key)
+        x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device="cuda") - 0.5
+        x[..., d.cin:] = 0
+        dy = torch.rand((d.batch, d.hout, d.wout, d.cout_p), device="cuda") - 0.5
+        dy[..., d.cout:] = 0
+        w = torch.rand((d.n_pad16, d.k_pad), device="cuda") - 0.5
+        b = torch.zeros(d.n_pad16, device="cuda")
+        wd = torch.rand((d.dn_pad16, d.dk_pad), device="cuda") - 0.5
+        y = torch.empty_like(dy)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty_like(b)
+        flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
+        line = "%-14s %3dx%-3d %3d->%-3d k%d M=%-7d" % (st.pname, d.hin, d.win, d.cin, d.cout, d.kh, d.batch * d.hout * d.wout)
+        for k in what:
+            if k == "dgrad" and not st.inputs[0].needs_grad:
+                line += "  dgrad   --           "
+                continue
+            if k == "fwd":
+                ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
+            elif k == "dgrad":
+                ms = timeit(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), a.iters)
+            else:
+                ms = timeit(lambda: ops.conv_bwd_weight(d, x, dy, dw=dw, dbias=db), a.iters)
+            tot[k] += ms
+            totf[k] += flops
+            line += "  %s %7.3f ms %6.1f TF" % (k, ms, flops / ms / 1e9)
+        print(line + ("  (dup shape)" if dup else ""), flush=True)
+    for k in what:
+        if tot[k]:
+            print("TOTAL %-6s %8.3f ms  %6.1f TF/s" % (k, tot[k], totf[k] / tot[k] / 1e9))
+    print("TOTAL all %8.3f ms" % sum(tot.values()))
+
+
+if __name__ == "__main__":
+    main()
