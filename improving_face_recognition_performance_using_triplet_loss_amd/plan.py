@@ -323,5 +323,17 @@ class Plan:
                 dx_input = dy
         return dx_input
 
+    def routing_inputs(self):
+        """{MFM / pooling node name -> its INPUT activation as an NCHW torch tensor} of the last forward(train=True);
+        lets a higher-precision checker follow the same arg-max routes (tests only)."""
+        out = {}
+        for st in self.steps:
+            if st.op in ("mfm", "pool"):
+                src = st.inputs[0]
+                t = self._acts[src.index]
+                c, h, w = src.shape
+                out[st.node.name] = ops.nhwc_to_nchw(t.view(self.batch, h, w, pad4(c)), c)
+        return out
+
     def release(self):
         self._acts = self._aux = None

@@ -335,11 +335,20 @@ class Tape:
         self.ops.append(fn)
 
 
-def efm29_forward(params, x, tape=None, in_channels=3):
+def efm29_forward(params, x, tape=None, in_channels=3, routing=None):
     """x: (B, C, H, W) -> 342-d post-fc1 MFM feature ('concat29_output', ref: final_efm.py:208).
-    With `tape`, records closures so that efm29_backward can run."""
+    With `tape`, records closures so that efm29_backward can run.
+
+    `routing` (optional): {node name -> tensor} whose arg-max / arg-min decisions the BACKWARD pass follows instead of
+    this run's own forward values (keys: 'efm<L>_res_in', 'efm<L>_res', 'efm<L>_r', 'efm<L>', 'pool<L>', 'concat29' =
+    the input of that MFM / pooling node).  max/min/pool gradients are piecewise constant in the forward values, so
+    an fp32 implementation whose forward differs in the last bit can legitimately take a different route; handing its
+    forward values in here makes the comparison of the backward arithmetic exact (see tests/test_e2e_gpu.py)."""
     acts = {}
     grads = {}
+
+    def R(key, val):
+        return np.asarray(routing[key]).reshape(val.shape) if routing is not None and key in routing else val
 
     def conv(name, inp, pad, residual=None):
         w, b = params[name + "_weight"], params[name + "_bias"]
@@ -362,7 +371,8 @@ def efm29_forward(params, x, tape=None, in_channels=3):
         e2 = mfm3(c1)
         out = conv("conv%s_res_r" % lname, e2, 1, residual=data)
         if tape is not None:
-            tape.ops[-2:] = [("res_block", lname, (tape.ops[-2][2], tape.ops[-1][2], data, c1))]
+            tape.ops[-2:] = [("res_block", lname, (tape.ops[-2][2], tape.ops[-1][2], R("efm%s_res_in" % lname, data),
+                                                   R("efm%s_res" % lname, c1)))]
         return out
 
     cur = x
@@ -375,18 +385,18 @@ def efm29_forward(params, x, tape=None, in_channels=3):
             cr = conv("conv%s_r" % layer, cur, 0)
             cur = mfm3(cr)
             if tape is not None:
-                tape.push(("mfm", layer + "_r", cr))
+                tape.push(("mfm", layer + "_r", R("efm%s_r" % layer, cr)))
         cv = conv("conv%s" % layer, cur, pad)
         mf = mfm3(cv)
         cur = maxpool2(mf)
         if tape is not None:
-            tape.push(("mfm_pool", layer, (cv, mf)))
+            tape.push(("mfm_pool", layer, (R("efm%s" % layer, cv), R("pool%s" % layer, mf))))
         acts["pool" + layer] = cur
     flat = cur
     fc1 = fully_connected(flat, params["fc1_weight"], params["fc1_bias"])
     feat = mfm3(fc1)
     if tape is not None:
-        tape.push(("fc1", "fc1", (flat, fc1)))
+        tape.push(("fc1", "fc1", (flat, R("concat29", fc1))))
         tape.grads = grads
     acts["fc1"] = fc1
     acts["feat"] = feat
@@ -433,14 +443,14 @@ def head_forward(w_head, feat, normalize="row"):
     return y @ w_head.T, (y, n)
 
 
-def train_step_loss(params, w_head, x, neg_idx, margin, in_channels=3, demb=None):
+def train_step_loss(params, w_head, x, neg_idx, margin, in_channels=3, demb=None, routing=None):
     """One reference-layout step: batch = [B/2 anchors ; B/2 positives], negatives = detached rows of the anchor
     half picked by `neg_idx` (ref: train_efm.py:232-241), loss vector (B/2,), head on row-normalised features.
     Returns (loss, emb, feat, grads, g_head).  With `demb` given, that upstream gradient replaces the loss's own
     (a well-conditioned probe of the backward pass: at random init all embeddings nearly coincide, so the loss
     gradient 2(n-p) is a difference of nearly equal fp32 numbers)."""
     tape = Tape()
-    feat, acts = efm29_forward(params, x, tape, in_channels)
+    feat, acts = efm29_forward(params, x, tape, in_channels, routing)
     emb, (yn, nrm) = head_forward(w_head, feat)
     h = x.shape[0] // 2
     a, p = emb[:h], emb[h:]

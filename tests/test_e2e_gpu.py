@@ -79,14 +79,14 @@ def test_mini_efm_step_vs_numpy_oracle():
     assert rel_err(s_ap.cpu().numpy(), r_ap) < TOL and rel_err(s_an.cpu().numpy(), r_an) < TOL
 
 
-def test_112_step_vs_torch_oracle():
-    """3x112x112 (the BASELINE geometry, 7->3 floor pooling included), B=8, torch-CPU fp64 oracle.
+def test_112_step_vs_oracles():
+    """3x112x112 (the BASELINE geometry, 7->3 floor pooling included), B=8.
 
-    Forward (feature, embedding, loss): 1e-3.  Gradients: max/min/pool route the gradient through arg-max
-    decisions, so a last-bit difference in a forward value can flip a route — a fp32 run of the SAME oracle on the
-    CPU differs from its fp64 run by ~5e-3 here.  The HIP path is therefore held to max(1e-3, 3x that fp32-CPU
-    noise floor), measured in the same test; kernel-level backward parity at 2e-4 is in test_kernels_gpu.py and
-    the flip-free mini network above holds 1e-3 end to end."""
+    Forward (feature, embedding, loss) against the torch-CPU fp64 oracle: 1e-3.
+    Backward against the NumPy fp64 oracle at 1e-3 with the arg-max routes of max/min/pool taken from the HIP
+    forward (`routing=`): those gradients are piecewise constant in the forward values, and a last-bit difference
+    between two correct forwards flips a few routes — the SAME oracle run in fp32 on the CPU differs from its own
+    fp64 run by ~6e-3 on these inputs (asserted below as the noise floor that makes the routing hand-over necessary)."""
     tr, params, w_head, x = _make(8, 112)
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     labels = synth.parity_labels(8, images_per_identity=2)
@@ -98,24 +98,26 @@ def test_112_step_vs_torch_oracle():
         twh = torch.tensor(w_head, dtype=dt, requires_grad=True)
         loss_r, emb_r, feat_r = OT.train_step(tp, twh, torch.tensor(x, dtype=dt), neg.long(), 0.2, demb=demb.to(dt))
         grads = {k: t.grad.double().numpy() for k, t in tp.items()}
-        grads["head_weight"] = twh.grad.double().numpy()
         ref[dt] = (loss_r.double().numpy(), emb_r.double().numpy(), feat_r.double().numpy(), grads)
-    loss_r, emb_r, feat_r, grads_r = ref[torch.float64]
+    loss_r, emb_r, feat_r, grads_t = ref[torch.float64]
     loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg.cuda())
     assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), feat_r) < TOL
     assert rel_err(tr.last["emb"].cpu().numpy(), emb_r) < TOL
     assert rel_err(loss.cpu().numpy(), loss_r) < TOL
+    routing = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.routing_inputs().items()}
     tr.backward(demb=demb.float().cuda())
     g = tr.plan.export_params(tr.grad)
-    floor = max(rel_err(ref[torch.float32][3][k], grads_r[k]) for k in grads_r)
-    bound = max(TOL, 3.0 * floor)
+    _, _, _, grads_r, ghead_r = O.train_step_loss(params, w_head, x, neg.numpy(), 0.2, demb=demb.numpy(), routing=routing)
     worst, worst_name = 0.0, None
     for name, r in grads_r.items():
         e = rel_err(g[name].cpu().numpy().reshape(r.shape), r)
         if e > worst:
             worst, worst_name = e, name
-    print("112 gradient parity: worst %.3e (%s), fp32-CPU noise floor %.3e" % (worst, worst_name, floor))
-    assert worst < bound, (worst, worst_name, floor)
+    floor = max(rel_err(ref[torch.float32][3][k], grads_t[k]) for k in grads_t)
+    print("112 gradient parity (same routes): worst %.3e (%s); fp32-vs-fp64 CPU oracle without route hand-over: %.3e"
+          % (worst, worst_name, floor))
+    assert worst < TOL, (worst, worst_name)
+    assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), ghead_r) < TOL
 
 
 def test_step_is_bitwise_reproducible():
