@@ -1,0 +1,55 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/efm_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from improving_face_recognition_performance_using_triplet_loss_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "efm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(efm_[a-z0-9_]+)\s*\(", text)
+    return [n for n in dict.fromkeys(names) if n not in ("efm_pad4", "efm_pad16")]
+
+
+def test_header_and_binding_list_the_same_entry_points():
+    assert sorted(_declared()) == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert _lib.load().efm_version() == 1
+
+
+def test_descriptor_and_error_convention_without_a_gpu():
+    d = _lib.conv_desc(256, 56, 56, 66, 198, 3, 3, 1, 1)
+    assert (d.hout, d.wout, d.cin_p, d.cout_p, d.n_pad16, d.k_pad) == (56, 56, 68, 200, 208, 624)
+    assert (d.dn_pad16, d.dk_pad) == (80, 1808)
+    fc = _lib.conv_desc(256, 3, 3, 174, 513, 3, 3, 0, 0)  # fc1 as a 3x3 'valid' convolution
+    assert (fc.hout, fc.wout, fc.k_pad, fc.n_pad16) == (1, 1, 1584, 528)
+    with pytest.raises(_lib.EfmError) as e:
+        _lib.conv_desc(1, 2, 2, 3, 8, 5, 5, 0, 0)
+    assert "kernel larger" in str(e.value)
+    lib = _lib.load()
+    assert lib.efm_conv_wgrad_workspace_bytes(ctypes.byref(d)) > 0
+    # a null pointer is refused with an error code, never a crash
+    assert lib.efm_mfm_fwd(None, None, 4, 99, 3, None) == -1
+    assert b"mfm_fwd" in lib.efm_last_error_string()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EfmError) as e:
+        _lib.load()
+    assert "no CPU fallback" in str(e.value).replace("There is no", "no")

@@ -1,0 +1,206 @@
+"""CPU tests of the oracle itself: hand-computed known answers for every [MX-assumed] operator semantic
+(SURVEY.md §8c), agreement of the two independent restatements, and the exact work counts of BASELINE.md.
+The reference holds no golden vectors for this path (parity unpinned), so these KATs are the pins."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import efm_oracle as O
+from oracle import efm_oracle_torch as OT
+
+
+def test_mfm3_kat_and_tie_rules():
+    # 1 x 6 x 1 x 2: slices s0 = ch0-1, s1 = ch2-3, s2 = ch4-5
+    x = np.array([[[[1.0, 5.0]], [[-2.0, 0.0]], [[3.0, 5.0]], [[4.0, 0.5]], [[3.0, 2.0]], [[-7.0, 0.5]]]])
+    y = O.mfm3(x)
+    # ch0: max(s0c0,s1c0,s2c0) = max(1,3,3)=3 ; max(5,5,2)=5 | ch1: max(-2,4,-7)=4 ; max(0,.5,.5)=.5
+    # ch2: min(1,3,3)=1 ; min(5,5,2)=2 | ch3: min(-2,4,-7)=-7 ; min(0,.5,.5)=0
+    assert np.array_equal(y[0, :, 0, :], np.array([[3, 5], [4, 0.5], [1, 2], [-7, 0]]))
+    g = np.arange(1, 9, dtype=float).reshape(1, 4, 1, 2)  # gmax = [[1,2],[3,4]], gmin = [[5,6],[7,8]]
+    d_group = O.mfm3_bwd(x, g, O.ORDER_GROUP)
+    d_res = O.mfm3_bwd(x, g, O.ORDER_RES)
+    # position (c0, w0): s = (1,3,3): max tie between s1 and s2. GROUP = max(max(s0,s1),s2): lhs (=s1 via max1) wins;
+    # RES = max(s2, max1): s2 wins.  min = s0 either way.
+    assert d_group[0, 2, 0, 0] == 1 and d_group[0, 4, 0, 0] == 0
+    assert d_res[0, 2, 0, 0] == 0 and d_res[0, 4, 0, 0] == 1
+    assert d_group[0, 0, 0, 0] == 5 and d_res[0, 0, 0, 0] == 5
+    # position (c0, w1): s = (5,5,2): max tie s0/s1 -> s0 (lhs of maximum(s0,s1)); min = s2
+    assert d_group[0, 0, 0, 1] == 2 and d_group[0, 2, 0, 1] == 0 and d_group[0, 4, 0, 1] == 6
+    # position (c1, w1): s = (0,.5,.5): max tie s1/s2, min = s0
+    assert d_group[0, 3, 0, 1] == 4 and d_res[0, 5, 0, 1] == 4 and d_group[0, 1, 0, 1] == 8
+    # gradient mass is conserved
+    assert d_group.sum() == g.sum() and d_res.sum() == g.sum()
+
+
+def test_mfm2_kat():
+    x = np.array([[[[1.0]], [[2.0]], [[2.0]], [[-1.0]]]])
+    assert np.array_equal(O.mfm2(x)[0, :, 0, 0], [2.0, 2.0])
+    d = O.mfm2_bwd(x, np.array([[[[10.0]], [[20.0]]]]))
+    assert np.array_equal(d[0, :, 0, 0], [0, 20, 10, 0])
+
+
+def test_conv_is_cross_correlation_with_bias():
+    x = np.arange(9, dtype=float).reshape(1, 1, 3, 3)
+    w = np.array([[[[1.0, 2.0], [3.0, 4.0]]]])
+    y = O.conv2d(x, w, np.array([0.5]), (0, 0))
+    # top-left: 0*1 + 1*2 + 3*3 + 4*4 + .5 = 27.5 (a true convolution would flip the kernel and give 13.5)
+    assert y.shape == (1, 1, 2, 2) and y[0, 0, 0, 0] == 27.5 and y[0, 0, 1, 1] == 4 * 1 + 5 * 2 + 7 * 3 + 8 * 4 + 0.5
+    yp = O.conv2d(x, np.ones((1, 1, 3, 3)), None, (1, 1))
+    assert yp.shape == (1, 1, 3, 3) and yp[0, 0, 0, 0] == 0 + 1 + 3 + 4 and yp[0, 0, 1, 1] == 36
+
+
+def test_conv_bwd_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    x, w, b = rng.normal(size=(2, 3, 5, 4)), rng.normal(size=(4, 3, 3, 3)), rng.normal(size=4)
+    dy = rng.normal(size=(2, 4, 5, 4))
+    dx, dw, db = O.conv2d_bwd(x, w, dy, (1, 1))
+    eps = 1e-6
+    for arr, grad, idx in ((x, dx, (1, 2, 3, 1)), (w, dw, (2, 1, 0, 2))):
+        old = arr[idx]
+        arr[idx] = old + eps
+        up = (O.conv2d(x, w, b, (1, 1)) * dy).sum()
+        arr[idx] = old - eps
+        dn = (O.conv2d(x, w, b, (1, 1)) * dy).sum()
+        arr[idx] = old
+        assert abs((up - dn) / (2 * eps) - grad[idx]) < 1e-6
+    assert np.allclose(db, dy.sum(axis=(0, 2, 3)))
+
+
+def test_pool_floor_7_to_3_and_first_max():
+    x = np.arange(49, dtype=float).reshape(1, 1, 7, 7)
+    y = O.maxpool2(x)
+    assert y.shape == (1, 1, 3, 3)  # 'valid' convention: the 7th row / column is dropped
+    assert y[0, 0, 0, 0] == 8 and y[0, 0, 2, 2] == 40
+    x2 = np.zeros((1, 1, 2, 2))
+    d = O.maxpool2_bwd(x2, np.array([[[[3.0]]]]))
+    assert d[0, 0, 0, 0] == 3 and d.sum() == 3  # all equal -> first in scan order
+    d7 = O.maxpool2_bwd(x, np.ones((1, 1, 3, 3)))
+    assert d7[0, 0, 6].sum() == 0 and d7[0, 0, :, 6].sum() == 0 and d7.sum() == 9
+
+
+def test_fully_connected_flattens_nchw():
+    x = np.arange(8, dtype=float).reshape(1, 2, 2, 2)
+    w = np.zeros((1, 8))
+    w[0, 5] = 1.0  # NCHW flatten: index 5 = channel 1, h 0, w 1
+    assert O.fully_connected(x, w, np.array([1.0]))[0, 0] == x[0, 1, 0, 1] + 1.0
+
+
+def test_norms():
+    x = np.array([[3.0, 4.0], [0.0, 2.0]])
+    y, n = O.l2norm_row(x)
+    assert np.allclose(n, [5, 2]) and np.allclose(y, [[0.6, 0.8], [0, 1]])
+    yf, nf = O.l2norm_frob(x)
+    assert math.isclose(nf, math.sqrt(29)) and np.allclose(yf, x / math.sqrt(29))
+    # backward of a unit-norm map is orthogonal to y
+    dy = np.array([[1.0, -2.0], [0.5, 0.25]])
+    dx = O.l2norm_row_bwd(y, n, dy)
+    assert np.allclose((dx * y).sum(1), 0)
+
+
+def test_triplet_loss_kat():
+    a, p, n = np.array([[0.0, 0.0], [0.0, 0.0]]), np.array([[1.0, 0.0], [0.1, 0.0]]), np.array([[0.0, 1.0], [2.0, 0.0]])
+    assert np.allclose(O.triplet_loss(a, p, n, 0.2), [0.2, 0.0])    # 1 - 1 + .2 ; .01 - 4 + .2 < 0 -> relu off
+    assert np.allclose(O.triplet_loss(a, p, n, 0.5), [0.5, 0.0])
+    da, dp, dn = O.triplet_loss_bwd(a, p, n, O.triplet_loss(a, p, n, 0.2), np.ones(2))
+    assert np.allclose(da[0], 2 * (n[0] - p[0])) and np.allclose(dp[0], 2 * p[0]) and np.allclose(dn[0], -2 * n[0])
+    assert not da[1].any() and not dp[1].any() and not dn[1].any()
+    # unit-norm rows: L = max(0, 2(d_ap - d_an) + m) with cosine distance d = 1 - cos  
+    rng = np.random.default_rng(1)
+    u = [v / np.linalg.norm(v, axis=1, keepdims=True) for v in rng.normal(size=(3, 4, 8))]
+    s_ap, s_an = O.cosine_dist(u[0], u[1], u[2])
+    assert np.allclose(O.triplet_loss(u[0], u[1], u[2], 0.2), np.maximum(2 * ((1 - s_ap) - (1 - s_an)) + 0.2, 0))
+
+
+def test_negative_pick_and_mining():
+    labels = np.array([0, 0, 1, 1])
+    assert np.array_equal(O.pick_negatives(labels, labels, [0, 1, 3, 2, 2, 0, 3, 1]), [3, 2, 0, 1])
+    e = np.array([[1.0, 0.0], [0.9, 0.1], [0.0, 1.0], [0.6, 0.8], [-1.0, 0.0]])
+    g = O.gram_cosine(e)
+    lab = np.array([0, 0, 1, 1, 2])
+    # anchor 0 / positive 1: d_ap ~ 0.006; negatives d: idx2 1.0, idx3 0.4, idx4 2.0 -> semi-hard (smallest above d_ap) = 3
+    assert O.mine_semihard(g, lab, [0], [1])[0] == 3
+    # anchor 2 / positive 3: d_ap = 0.2; all other-label d: idx0 1.0, idx1 ~.89, idx4 1.0 -> 1
+    assert O.mine_semihard(g, lab, [2], [3])[0] == 1
+    assert O.mine_semihard(g[:2, :2], np.array([0, 0]), [0], [1])[0] == -1
+
+
+def test_optimisers_and_schedule():
+    w, g = np.array([1.0, -2.0]), np.array([0.5, 0.25])
+    assert np.allclose(O.sgd_step(w, g, 0.1, 0.01, 0.5), w - 0.1 * (0.5 * g + 0.01 * w))
+    w1, m1, v1 = O.adam_step(w, g, np.zeros(2), np.zeros(2), 1, 0.001, 0.0, 1.0)
+    # first Adam step moves every weight by ~lr against the gradient sign
+    assert np.allclose(w1, w - 0.001 * np.sign(g), atol=1e-6)
+    assert O.factor_scheduler(1.0, 5, 6, 0.88) == 1.0 and math.isclose(O.factor_scheduler(1.0, 7, 6, 0.88), 0.88)
+    assert math.isclose(O.factor_scheduler(1.0, 13, 6, 0.88), 0.88 ** 2)
+
+
+def test_softmax_ce():
+    z = np.array([[1.0, 2.0, 3.0]])
+    l = O.softmax_cross_entropy(z, np.array([2]))
+    assert math.isclose(l[0], -math.log(math.exp(3) / (math.exp(1) + math.exp(2) + math.exp(3))))
+    d = O.softmax_cross_entropy_bwd(z, np.array([2]), np.ones(1))
+    assert math.isclose(d.sum(), 0.0, abs_tol=1e-12) and d[0, 2] < 0
+
+
+def test_efm29_table_matches_survey_counts():
+    layers = O.efm29_layers(3)
+    assert len(layers) == 29
+    names = [l[0] for l in layers]
+    assert names[:5] == ["conv1", "conv2_res", "conv2_res_r", "conv2_r", "conv2"] and "conv31_res_r" in names and names[-1] == "conv5"
+    shapes = O.efm29_param_shapes(3, 112)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 9068013
+    sizes = {"1": 112, "2": 56, "3": 28, "4": 14, "5": 7}
+    flops = 0
+    for name, co, ci, kh, kw, _ in layers:
+        hw = sizes[name[4]] ** 2
+        flops += 2 * hw * co * ci * kh * kw
+    assert flops == 5145993720
+    assert flops + 2 * 513 * 1566 == 5147600436
+    assert 3 * (flops + 2 * 513 * 1566) - 2 * 112 * 112 * 99 * 3 * 25 == 15256522908
+
+
+def test_numpy_and_torch_restatements_agree():
+    shapes = O.efm29_param_shapes(3, 32)
+    params = O.init_params(shapes, 42)
+    x = O.uniform01(4 * 3 * 32 * 32, 1234).reshape(4, 3, 32, 32)
+    wh = O.uniform_pm((128, 342), 777, O.xavier_uniform_scale((128, 342)))
+    neg = np.array([1, 0], dtype=np.int32)
+    demb = np.random.default_rng(3).uniform(-1, 1, (4, 128))
+    loss, emb, feat, grads, gh = O.train_step_loss(params, wh, x, neg, 0.2, demb=demb)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    twh = torch.tensor(wh, dtype=torch.float64, requires_grad=True)
+    tl, te, tf = OT.train_step(tp, twh, torch.tensor(x), torch.tensor(neg.astype(np.int64)), 0.2, demb=torch.tensor(demb))
+
+    def rel(a, b):
+        return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+    assert rel(feat, tf.numpy()) < 1e-10 and rel(emb, te.numpy()) < 1e-10 and rel(loss, tl.numpy()) < 1e-10
+    assert max(rel(grads[k], tp[k].grad.numpy()) for k in params) < 1e-5     # <= 1e-5 before freezing
+    assert rel(gh, twh.grad.numpy()) < 1e-5
+    # routing hand-over with the run's own values is the identity
+    _, _, _, grads2, _ = O.train_step_loss(params, wh, x, neg, 0.2, demb=demb, routing={})
+    assert all(np.array_equal(grads[k], grads2[k]) for k in grads)
+
+
+def test_xavier_and_generator_are_portable():
+    assert math.isclose(O.xavier_uniform_scale((128, 342)), math.sqrt(3.0 / ((342 + 128) / 2.0)))
+    assert math.isclose(O.xavier_uniform_scale((99, 3, 5, 5)), math.sqrt(3.0 / ((75 + 2475) / 2.0)))
+    u = O.uniform01(5, 1234)
+    # frozen values of the splitmix64 stream (seed 1234): any platform / numpy version must reproduce them
+    assert np.array_equal(u, O.uniform01(7, 1234)[:5]) and (0 <= u).all() and (u < 1).all()
+    assert np.array_equal((u * (1 << 24)).astype(np.int64), (u * (1 << 24)).round().astype(np.int64))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_lfw_protocol_perfectly_separable(metric):
+    rng = np.random.default_rng(0)
+    e1 = rng.normal(size=(60, 16))
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    same = np.arange(60) % 2 == 0
+    near = e1 + 0.05 * rng.normal(size=e1.shape)  # not exactly equal: arccos(1 + 1e-16) is NaN in the reference too
+    near /= np.linalg.norm(near, axis=1, keepdims=True)
+    e2 = np.where(same[:, None], near, -near)
+    tpr, fpr, acc = O.lfw_roc(np.arange(0, 4, 0.01), e1, e2, same, nrof_folds=10, metric=metric)
+    assert acc.mean() > 0.95 and tpr[-1] == 1.0 and fpr[0] == 0.0  # first-best-threshold rule can miss a test pair
