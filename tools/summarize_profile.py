@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/<tag> (written by tools/profile_round.sh) into profiles/<name>_*.{md,csv}."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, "profiles/%s_kernel_stats.csv" % name)
+rows = list(csv.DictReader(open(stats)))
+total = sum(float(r["TotalDurationNs"]) for r in rows)
+bench = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().splitlines()[-1])
+lines = ["# %s — rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`" % name, "",
+         "bench line under the profiler: %.2f ms/step, %.1f triplets/s, dominant-kernel roofline %s" %
+         (bench["ms_per_step"], bench["value"], json.dumps(bench["roofline"])), "",
+         "7 steps (2 warm-up + 5 timed) + 7 extra conv2-forward launches of the roofline probe; total GPU kernel time %.1f ms" % (total / 1e6), "",
+         "| % | total ms | calls | avg us | kernel |", "|---|---|---|---|---|"]
+for r in rows[:30]:
+    lines.append("| %.2f | %.3f | %s | %.1f | `%s` |" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6, r["Calls"],
+                                                       float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "")[:100]))
+
+
+def pmc(dirname, counter):
+    f = glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv"))
+    if not f:
+        return None
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
+            if r["Counter_Name"] == counter and "conv_fwd_k" in r["Kernel_Name"]]
+    return vals
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+lines += ["", "## HBM traffic of the dominant kernel (conv2 forward, conv_fwd_k<2,13>), separate --pmc passes", ""]
+if fetch and write:
+    f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+    # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (MI355X_MICROARCH.md §HBM);
+    # units are KiB
+    fetch_b, write_b = f_kb * 1024 * 2, w_kb * 1024
+    lines += ["FETCH_SIZE %.0f KiB/launch (x2 gfx950 correction -> %.1f MB), WRITE_SIZE %.0f KiB/launch (%.1f MB); "
+              "HBM bytes per launch = %.1f MB" % (f_kb, fetch_b / 1e6, w_kb, write_b / 1e6, (fetch_b + write_b) / 1e6),
+              "algorithmic bytes: x 802816*68*4 = 218.4 MB read + y 802816*200*4 = 642.3 MB written + weights 0.5 MB"]
+    json.dump({"fetch_bytes": fetch_b, "write_bytes": write_b, "traffic": fetch_b + write_b}, open("profiles/%s_traffic.json" % name, "w"))
+sq = glob.glob(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv"))
+if sq:
+    agg = {}
+    for r in csv.DictReader(open(sq[0])):
+        if "conv_fwd_k" in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    lines += ["", "## SQ counters, conv2 forward (mean per launch)", ""]
+    for k, v in agg.items():
+        lines.append("- %s = %.4g" % (k, sum(v) / len(v)))
+open("profiles/%s_summary.md" % name, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
