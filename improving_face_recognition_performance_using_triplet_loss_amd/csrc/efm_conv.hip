@@ -37,13 +37,23 @@ struct ConvP {
   int kh, kw, pad_h, pad_w;
   int n_pad16, k_pad, ksteps;
   int nblocks;
+  unsigned magic_c, magic_kw;  // ceil(2^32 / cin_p), ceil(2^32 / kw): exact k / cin_p and tap / kw for k < 2^16
+  unsigned x_bytes, w_bytes;
 };
 
-template <int MT, int NT>
-__global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define EFM_OOB 0x80000000u  // a byte offset no tensor reaches: the buffer range check then returns zeros
+
+// DMA = true : operands go global -> LDS directly (buffer_load ... lds, no VGPR staging, no ds_write);
+// DMA = false: global -> VGPR -> ds_write_b128.  Either way every load is an unconditional buffer load whose
+// out-of-image / out-of-matrix lanes carry an out-of-range offset (hardware zero fill): no divergent branch in the
+// K loop, so the compiler is free to schedule the loads among the MFMAs.
+// (The body lives in a __device__ function: the buffer-resource builtins only exist in the device pass, and a
+// __global__ template that names them directly loses its host-side launch stub.)
+template <int MT, int NT, bool DMA>
+__device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   constexpr int BM = MT * 64, BN = NT * 16;
   constexpr int PB = (NT * 64 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -55,10 +65,14 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
   const int mb = lid / p.nblocks, nb = lid - mb * p.nblocks;
   const int m0 = mb * BM, n0 = nb * BN;
 
-  // ---- staging coordinates: thread -> (row = tid/4 (+64 per pass), 16-byte piece kc = tid%4)
-  const int lrow = tid >> 2, kc = tid & 3;
-  int a_hi0[MT], a_wi0[MT];
-  long a_base[MT];
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // ---- staging coordinates: thread -> row = tid/4 (+64 per pass), LDS slot = tid%4 of that row's 64 bytes.
+  // The slot holds K piece kc = slot ^ g(row/4 % 4) (XOR swizzle, see file header).
+  const int lrow = tid >> 2, slot = tid & 3;
+  const int kc4 = (slot ^ swz_g((lrow >> 2) & 3)) * 4;
+  int a_hi0[MT], a_wi0[MT], a_base[MT];
   const int hw = p.hout * p.wout;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -69,58 +83,54 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
     const int ho = r / p.wout, wo = r - ho * p.wout;
     a_hi0[j] = ok ? ho - p.pad_h : -(1 << 20);
     a_wi0[j] = wo - p.pad_w;
-    a_base[j] = ((long)(b * p.hin + ho - p.pad_h) * p.win + (wo - p.pad_w)) * p.cin_p;
+    a_base[j] = ((b * p.hin + ho - p.pad_h) * p.win + (wo - p.pad_w)) * p.cin_p;
   }
-  int c = kc * 4, kh_ = 0, kw_ = 0;
-  while (c >= p.cin_p) {
-    c -= p.cin_p;
-    if (++kw_ == p.kw) { kw_ = 0; ++kh_; }
-  }
-  const float* b_ptr[PB];
-  bool b_ok[PB];
+  unsigned b_off[PB];
 #pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const int brow = lrow + 64 * j;
-    const int n = n0 + brow;
-    b_ok[j] = (brow < BN) && (n < p.n_pad16);
-    b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * p.k_pad + kc * 4;
-  }
+  for (int j = 0; j < PB; ++j) b_off[j] = (unsigned)(((n0 + lrow + 64 * j) * p.k_pad + kc4) * 4);
+  const int taps = p.kh * p.kw;
 
-  f32x4 ra[MT], rb[PB];
-  auto load_tile = [&](int t) {
-    const bool tap_ok = kh_ < p.kh;
-    const int doff = (kh_ * p.win + kw_) * p.cin_p + c;
+  u32x4 ra[MT], rb[PB];
+  auto a_offset = [&](int t, int j, unsigned kh_, unsigned kw_, int doff, bool tap_ok) -> unsigned {
+    const int hi = a_hi0[j] + (int)kh_, wi = a_wi0[j] + (int)kw_;
+    const bool v = tap_ok && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
+    return v ? (unsigned)((a_base[j] + doff) * 4) : EFM_OOB;
+  };
+  auto load_tile = [&](int t, int buf) {
+    const unsigned k = (unsigned)(t * 16 + kc4);
+    const unsigned tap = __umulhi(k, p.magic_c);
+    const int c = (int)(k - tap * (unsigned)p.cin_p);
+    const unsigned kh_ = __umulhi(tap, p.magic_kw), kw_ = tap - kh_ * (unsigned)p.kw;
+    const bool tap_ok = (int)tap < taps;
+    const int doff = ((int)kh_ * p.win + (int)kw_) * p.cin_p + c;
+    if (DMA) {
+      float* As = smem + buf * (BM + BN) * 16;
+      float* Bs = As + BM * 16;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int hi = a_hi0[j] + kh_, wi = a_wi0[j] + kw_;
-      const bool v = tap_ok && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + a_base[j] + doff) : z;
-    }
+      for (int j = 0; j < MT; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(As + (64 * j + 16 * wave) * 16),
+                                                 16, a_offset(t, j, kh_, kw_, doff, tap_ok), 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      rb[j] = b_ok[j] ? *reinterpret_cast<const f32x4*>(b_ptr[j] + t * 16) : z;
-    }
-    c += 16;
-    while (c >= p.cin_p) {
-      c -= p.cin_p;
-      if (++kw_ == p.kw) { kw_ = 0; ++kh_; }
+      for (int j = 0; j < PB; ++j)
+        if (64 * j + 16 * wave < BN)  // wave-uniform: a wave stages 16 whole rows
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Bs + (64 * j + 16 * wave) * 16),
+                                                   16, b_off[j] + (unsigned)(t * 64), 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_offset(t, j, kh_, kw_, doff, tap_ok), 0, 0);
+#pragma unroll
+      for (int j = 0; j < PB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, b_off[j] + (unsigned)(t * 64), 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
+    if (DMA) return;
     float* As = smem + buf * (BM + BN) * 16;
     float* Bs = As + BM * 16;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int row = lrow + 64 * j;
-      *reinterpret_cast<f32x4*>(As + (row * 4 + (kc ^ swz_g((row >> 2) & 3))) * 4) = ra[j];
-    }
+    for (int j = 0; j < MT; ++j) *reinterpret_cast<u32x4*>(As + ((lrow + 64 * j) * 4 + slot) * 4) = ra[j];
 #pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      const int row = lrow + 64 * j;
-      if (row < BN) *reinterpret_cast<f32x4*>(Bs + (row * 4 + (kc ^ swz_g((row >> 2) & 3))) * 4) = rb[j];
-    }
+    for (int j = 0; j < PB; ++j)
+      if (lrow + 64 * j < BN) *reinterpret_cast<u32x4*>(Bs + ((lrow + 64 * j) * 4 + slot) * 4) = rb[j];
   };
 
   f32x4 acc[MT][NT];
@@ -157,15 +167,15 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
     }
   };
 
-  load_tile(0);
+  load_tile(0, 0);
   store_tile(0);
   __syncthreads();
   for (int t = 0; t < p.ksteps; ++t) {
     const bool more = t + 1 < p.ksteps;
-    if (more) load_tile(t + 1);
+    if (more) load_tile(t + 1, (t + 1) & 1);
     compute(t & 1);
     if (more) store_tile((t + 1) & 1);
-    __syncthreads();
+    __syncthreads();  // (with DMA in flight hipcc drains vmcnt(0) here: the next tile has landed)
   }
 
   // ---- epilogue: D[row = 4*fq + r][col = fi] per 16x16 tile; + bias (+ residual)
@@ -191,6 +201,12 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
   }
 }
 
+template <int MT, int NT, bool DMA>
+__global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (MT * 64 + NT * 16) * 16];
+  conv_fwd_body<MT, NT, DMA>(p, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient.  C[n][k] = sum_m dy[m][n] * A[m][k].  MFMA A operand = dy (rows = n),
 // B operand = im2col(x) (cols = k) so that a result register holds 16 consecutive k of one n
@@ -209,18 +225,27 @@ struct WgradP {
   int n_pad16, k_pad;
   int kblocks, nblocks, splits;
   int m_per_split;
+  unsigned x_bytes, y_bytes;
 };
 
+// Exact m / d for 0 <= m < 2^23 via a float reciprocal and a one-step fix-up (branch free).
+__device__ __forceinline__ int fdiv(int m, int d, float inv) {
+  int q = (int)((float)m * inv);
+  int r = m - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
 template <int KPW, int NTW>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   constexpr int BKR = 64 * KPW, BNW = 16 * NTW, BP = 16;
-  constexpr int SX = BKR + 16;                          // stride % 32 == 16 -> conflict-free b32 reads
-  constexpr int SY = (BNW % 32 == 16) ? BNW : BNW + 16;
-  constexpr int PX = KPW;                               // x pieces per thread
-  constexpr int PY = (NTW * 64 + 255) / 256;            // dy pieces per thread
-  constexpr int K4 = BKR / 4;                           // 16-byte pieces per pixel row of the x tile
+  constexpr int PX = KPW;                     // x pieces per thread per step
+  constexpr int PY = (NTW * 64 + 255) / 256;  // dy pieces per thread per step
+  constexpr int K4 = BKR / 4;                 // 16-byte pieces per pixel row of the x tile
   constexpr int N4 = BNW / 4;
-  __shared__ __attribute__((aligned(16))) float smem[2 * BP * (SX + SY)];
+  constexpr bool SWZ_Y = (NTW % 2 == 0);      // odd NTW: row stride = 16 (mod 32) floats, already conflict free
+  constexpr int TILE = BP * (BKR + BNW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
@@ -232,55 +257,51 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int hw = p.hout * p.wout;
+  const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.wout;
 
-  // x pieces: fixed (tap, channel) per thread for the whole kernel, pixel varies per step.
-  const int xk4 = tid % K4, xp0 = tid / K4;  // pixel rows xp0 + (256/K4)*j
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.y_bytes, 0x00020000);
+
+  // LDS image: Xs[pixel][BKR], Ys[pixel][BNW], no padding (an LDS-DMA wave instruction writes 1 KiB contiguously);
+  // bank conflicts of the 4-pixel fragment reads are removed by XOR-ing the 16-byte piece index with 4*(pixel&1),
+  // applied on the SOURCE address here and on the read address below.
+  // x pieces: e = tid + 256 j -> pixel e / K4, LDS piece e % K4; (tap, channel) is fixed per thread.
+  const int xpiece = tid % K4, xp0 = tid / K4;
+  const int xk4 = xpiece ^ (4 * (xp0 & 1));
   const int kglob = k0 + xk4 * 4;
   const int tap = kglob / p.cin_p, xc = kglob - tap * p.cin_p;
   const int xkh = tap / p.kw, xkw = tap - xkh * p.kw;
   const bool xtap_ok = tap < p.kh * p.kw;
   const int xdoff = ((xkh - p.pad_h) * p.win + (xkw - p.pad_w)) * p.cin_p + xc;
 
-  f32x4 rx[PX], ry[PY];
-  auto load_tile = [&](int step) {
+  auto load_tile = [&](int step, int buf) {
+    float* Xs = smem + buf * TILE;
+    float* Ys = Xs + BP * BKR;
     const int mbase = m_begin + step * BP;
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
       const int m = mbase + xp0 + (256 / K4) * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xtap_ok && m < m_end) {
-        const int b = m / hw, r = m - b * hw;
-        const int ho = r / p.wout, wo = r - ho * p.wout;
-        const int hi = ho - p.pad_h + xkh, wi = wo - p.pad_w + xkw;
-        if ((unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win)
-          v = *reinterpret_cast<const f32x4*>(p.x + ((long)(b * p.hin + ho) * p.win + wo) * p.cin_p + xdoff);
+      const int b = fdiv(m, hw, inv_hw), r = m - b * hw;
+      const int ho = fdiv(r, p.wout, inv_w), wo = r - ho * p.wout;
+      const int hi = ho - p.pad_h + xkh, wi = wo - p.pad_w + xkw;
+      const bool v = xtap_ok && m < m_end && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
+      const unsigned off = v ? (unsigned)((((b * p.hin + ho) * p.win + wo) * p.cin_p + xdoff) * 4) : EFM_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(Xs + (256 * j + 64 * wave) * 4),
+                                               16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < PY; ++j) {
+      if (256 * j + 64 * wave < BP * N4) {  // wave-uniform
+        const int e = tid + 256 * j;
+        const int pp = e / N4;
+        int n4 = e - pp * N4;
+        if (SWZ_Y) n4 ^= 4 * (pp & 1);
+        const int m = mbase + pp, n = n0 + n4 * 4;
+        const bool v = m < m_end && n < p.cout_p;
+        const unsigned off = v ? (unsigned)((m * p.cout_p + n) * 4) : EFM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(Ys + (256 * j + 64 * wave) * 4),
+                                                 16, off, 0, 0, 0);
       }
-      rx[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < PY; ++j) {
-      const int e = tid + 256 * j;
-      const int pp = e / N4, n4 = e - pp * N4;
-      const int m = mbase + pp, n = n0 + n4 * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (e < BP * N4 && m < m_end && n < p.cout_p)
-        v = *reinterpret_cast<const f32x4*>(p.dy + (long)m * p.cout_p + n);
-      ry[j] = v;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* Xs = smem + buf * BP * (SX + SY);
-    float* Ys = Xs + BP * SX;
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-      const int pp = xp0 + (256 / K4) * j;
-      *reinterpret_cast<f32x4*>(Xs + pp * SX + xk4 * 4) = rx[j];
-    }
-#pragma unroll
-    for (int j = 0; j < PY; ++j) {
-      const int e = tid + 256 * j;
-      const int pp = e / N4, n4 = e - pp * N4;
-      if (e < BP * N4) *reinterpret_cast<f32x4*>(Ys + pp * SY + n4 * 4) = ry[j];
     }
   };
 
@@ -291,6 +312,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
     for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fq = lane >> 4;
+  const int fx = 16 * (fq & 1);  // the read-side half of the XOR swizzle (16 floats = 4 pieces)
   // bias gradient rides along: the MFMA A operand IS dy, so wave 0 of the first k-block keeps a running
   // column sum of what it feeds to the matrix core (no second pass over dy, no atomics).
   const bool do_bias = (p.bias_part != nullptr) && (kb == 0) && (wave == 0);
@@ -298,16 +320,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
 #pragma unroll
   for (int b = 0; b < NTW; ++b) bsum[b] = 0.f;
   auto compute = [&](int buf) {
-    const float* Xs = smem + buf * BP * (SX + SY);
-    const float* Ys = Xs + BP * SX;
+    const float* Xs = smem + buf * TILE;
+    const float* Ys = Xs + BP * BKR;
 #pragma unroll
     for (int s = 0; s < BP / 4; ++s) {
       float bx[KPW];
 #pragma unroll
-      for (int kt = 0; kt < KPW; ++kt) bx[kt] = Xs[(4 * s + fq) * SX + (wave * KPW + kt) * 16 + fi];
+      for (int kt = 0; kt < KPW; ++kt) bx[kt] = Xs[(4 * s + fq) * BKR + (((wave * KPW + kt) * 16 + fi) ^ fx)];
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const float ay = Ys[(4 * s + fq) * SY + nt * 16 + fi];
+        const float ay = Ys[(4 * s + fq) * BNW + (SWZ_Y ? ((nt * 16 + fi) ^ fx) : (nt * 16 + fi))];
         bsum[nt] += do_bias ? ay : 0.f;
 #pragma unroll
         for (int kt = 0; kt < KPW; ++kt)
@@ -317,17 +339,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
   };
 
   const int steps = (m_end - m_begin + BP - 1) / BP;
-  if (steps > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  if (steps > 0) load_tile(0, 0);
   __syncthreads();
   for (int t = 0; t < steps; ++t) {
-    const bool more = t + 1 < steps;
-    if (more) load_tile(t + 1);
+    if (t + 1 < steps) load_tile(t + 1, (t + 1) & 1);
     compute(t & 1);
-    if (more) store_tile((t + 1) & 1);
-    __syncthreads();
+    __syncthreads();  // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
   }
 
   if (do_bias) {
@@ -355,6 +372,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
       }
     }
   }
+}
+
+template <int KPW, int NTW>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 16 * (64 * KPW + 16 * NTW)];
+  conv_wgrad_body<KPW, NTW>(p, smem);
 }
 
 // out[g][i] = sum_{s in group g} ws[s*stride + i] (+ out[i] when accumulating), fixed order (deterministic).
@@ -438,12 +461,12 @@ int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-template <int MT>
+template <int MT, bool DMA>
 int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<MT, N>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<MT, N, DMA>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
 #undef EFM_CASE
@@ -481,7 +504,16 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   const int BM = 64 * MT;
   const long mblocks = efm::cdiv(p.M, BM);
   dim3 grid((unsigned)(mblocks * p.nblocks));
-  int rc = (MT == 2) ? launch_fwd_nt<2>(NT, grid, s, p) : launch_fwd_nt<1>(NT, grid, s, p);
+  p.magic_c = (unsigned)((0x100000000ULL + (unsigned)cin_p - 1) / (unsigned)cin_p);
+  p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)kw - 1) / (unsigned)kw);
+  p.x_bytes = (unsigned)((size_t)batch * hin * win * cin_p * sizeof(float));
+  p.w_bytes = (unsigned)((size_t)n_pad16 * k_pad * sizeof(float));
+  const bool dma = env_int("EFM_CONV_DMA", 1) != 0;
+  int rc;
+  if (dma)
+    rc = (MT == 2) ? launch_fwd_nt<2, true>(NT, grid, s, p) : launch_fwd_nt<1, true>(NT, grid, s, p);
+  else
+    rc = (MT == 2) ? launch_fwd_nt<2, false>(NT, grid, s, p) : launch_fwd_nt<1, false>(NT, grid, s, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_fwd");
 }
@@ -554,8 +586,11 @@ int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, i
   d->k_pad = efm_pad16(kh * kw * d->cin_p);
   d->dn_pad16 = efm_pad16(cin);
   d->dk_pad = efm_pad16(kh * kw * d->cout_p);
-  EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 31) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 31),
-              "conv_desc_init: tensor exceeds 2^31 elements");
+  EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 30) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 30),
+              "conv_desc_init: tensor exceeds 2^30 elements (4 GiB buffer descriptors)");
+  EFM_REQUIRE(d->k_pad < 65536 && d->dk_pad < 65536, "conv_desc_init: K = kh*kw*channels must stay below 65536");
+  EFM_REQUIRE((long)batch * d->hout * d->wout < (1L << 23) && (long)batch * hin * win < (1L << 23),
+              "conv_desc_init: batch*H*W must stay below 2^23 pixels");
   return EFM_OK;
 }
 
@@ -616,6 +651,8 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad;
   p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
+  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
+  p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * d->cout_p * sizeof(float));
   float* slabs = (float*)workspace;
   float* lvl2 = slabs + pl.slab_floats;
   float* bpart = lvl2 + pl.lvl2_floats;
