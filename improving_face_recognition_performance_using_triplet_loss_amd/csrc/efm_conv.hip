@@ -225,6 +225,7 @@ struct WgradP {
   int n_pad16, k_pad;
   int kblocks, nblocks, splits;
   int m_per_split;
+  int mma_blocks;
   unsigned x_bytes, y_bytes;
 };
 
@@ -313,12 +314,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
 
   const int fi = lane & 15, fq = lane >> 4;
   const int fx = 16 * (fq & 1);  // the read-side half of the XOR swizzle (16 floats = 4 pieces)
-  // bias gradient rides along: the MFMA A operand IS dy, so wave 0 of the first k-block keeps a running
-  // column sum of what it feeds to the matrix core (no second pass over dy, no atomics).
-  const bool do_bias = (p.bias_part != nullptr) && (kb == 0) && (wave == 0);
-  float bsum[NTW];
-#pragma unroll
-  for (int b = 0; b < NTW; ++b) bsum[b] = 0.f;
   auto compute = [&](int buf) {
     const float* Xs = smem + buf * TILE;
     const float* Ys = Xs + BP * BKR;
@@ -330,7 +325,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const float ay = Ys[(4 * s + fq) * BNW + (SWZ_Y ? ((nt * 16 + fi) ^ fx) : (nt * 16 + fi))];
-        bsum[nt] += do_bias ? ay : 0.f;
 #pragma unroll
         for (int kt = 0; kt < KPW; ++kt)
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bx[kt], acc[kt][nt], 0, 0, 0);
@@ -347,16 +341,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
     __syncthreads();  // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
   }
 
-  if (do_bias) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      float v = bsum[nt];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int n = n0 + nt * 16 + fi;
-      if (fq == 0 && n < p.n_pad16) p.bias_part[(long)split * p.n_pad16 + n] = v;
-    }
-  }
   float* ws = p.ws + (long)split * p.n_pad16 * p.k_pad;
 #pragma unroll
   for (int kt = 0; kt < KPW; ++kt) {
@@ -374,10 +358,48 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   }
 }
 
+// Bias gradient: the blocks past the matrix-core grid each column-sum BIAS_ROWS rows of dy (pure streaming work that
+// fills the tail of the launch; dy is being pulled through L2 by the MFMA blocks anyway).  Partials are reduced in a
+// fixed order by slab_reduce_k: no atomics.
+constexpr int BIAS_ROWS = 1024;
+__device__ __forceinline__ void bias_colsum_body(const WgradP& p, float* smem, int chunk) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int m_begin = chunk * BIAS_ROWS, m_end = min(p.M, m_begin + BIAS_ROWS);
+  const int ng = p.cout_p >> 2, ng16 = p.n_pad16 >> 2;
+  for (int g0 = 0; g0 < ng16; g0 += 64) {
+    const int g = g0 + cx;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (g < ng) {
+      const float* base = p.dy + g * 4;
+      int m = m_begin + ry;
+      for (; m + 12 < m_end; m += 16) {
+        s0 += *reinterpret_cast<const f32x4*>(base + (long)m * p.cout_p);
+        s1 += *reinterpret_cast<const f32x4*>(base + (long)(m + 4) * p.cout_p);
+        s2 += *reinterpret_cast<const f32x4*>(base + (long)(m + 8) * p.cout_p);
+        s3 += *reinterpret_cast<const f32x4*>(base + (long)(m + 12) * p.cout_p);
+      }
+      for (; m < m_end; m += 4) s0 += *reinterpret_cast<const f32x4*>(base + (long)m * p.cout_p);
+    }
+    *reinterpret_cast<f32x4*>(smem + (ry * 64 + cx) * 4) = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && g < ng16) {
+      f32x4 t = *reinterpret_cast<f32x4*>(smem + cx * 4);
+      t += *reinterpret_cast<f32x4*>(smem + (64 + cx) * 4);
+      t += *reinterpret_cast<f32x4*>(smem + (128 + cx) * 4);
+      t += *reinterpret_cast<f32x4*>(smem + (192 + cx) * 4);
+      *reinterpret_cast<f32x4*>(p.bias_part + (long)chunk * p.n_pad16 + g * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
 template <int KPW, int NTW>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_k(const WgradP p) {
+__global__ void __launch_bounds__(256, 3) conv_wgrad_k(const WgradP p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 16 * (64 * KPW + 16 * NTW)];
-  conv_wgrad_body<KPW, NTW>(p, smem);
+  if ((int)blockIdx.x >= p.mma_blocks)
+    bias_colsum_body(p, smem, (int)blockIdx.x - p.mma_blocks);
+  else
+    conv_wgrad_body<KPW, NTW>(p, smem);
 }
 
 // out[g][i] = sum_{s in group g} ws[s*stride + i] (+ out[i] when accumulating), fixed order (deterministic).
@@ -497,8 +519,9 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   const int nblocks = (tiles + 12) / 13;
   const int NT = round_nt((tiles + nblocks - 1) / nblocks);
   p.nblocks = (tiles + NT - 1) / NT;
-  int MT = 2;
-  // keep at least ~4 blocks per CU in flight; small problems use the 64-row tile
+  // 64-row tiles (52 accumulator registers at NT = 13 -> 4 blocks per CU) measured equal or better than 128-row
+  // tiles for NT >= 7; narrow tiles (NT <= 6) amortise the pixel-tile staging better with 128 rows.
+  int MT = (NT >= 7) ? 1 : 2;
   if ((long)efm::cdiv(p.M, 128) * p.nblocks < 1024) MT = 1;
   MT = env_int("EFM_CONV_MT", MT);
   const int BM = 64 * MT;
@@ -533,7 +556,7 @@ int launch_wgrad_nt(int NTW, dim3 grid, hipStream_t s, const WgradP& p) {
 }
 
 struct WgradPlan {
-  int KPW, NTW, kblocks, nblocks, splits, m_per_split, groups, per_group;
+  int KPW, NTW, kblocks, nblocks, splits, m_per_split, groups, per_group, bias_chunks, bias_groups;
   size_t slab_floats, lvl2_floats, ws_floats;  // wgrad slabs | second-level slabs | + bias partials (both levels)
 };
 
@@ -562,7 +585,9 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.groups = (pl.splits + pl.per_group - 1) / pl.per_group;
   pl.slab_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad;
   pl.lvl2_floats = (pl.groups > 1) ? (size_t)pl.groups * d->n_pad16 * d->k_pad : 0;
-  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.splits + pl.groups) * d->n_pad16;
+  pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
+  pl.bias_groups = (pl.bias_chunks + 31) / 32;
+  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.bias_chunks + pl.bias_groups) * d->n_pad16;
   return pl;
 }
 
@@ -656,26 +681,28 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   float* slabs = (float*)workspace;
   float* lvl2 = slabs + pl.slab_floats;
   float* bpart = lvl2 + pl.lvl2_floats;
-  float* bpart2 = bpart + (size_t)pl.splits * d->n_pad16;
+  float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
   p.bias_part = dbias ? bpart : nullptr;
-  dim3 grid((unsigned)(pl.kblocks * pl.nblocks * pl.splits));
+  p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
+  dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
   if (rc != EFM_OK) return rc;
   rc = efm::check_launch("conv_wgrad");
   if (rc != EFM_OK) return rc;
-  auto reduce = [&](const float* in, float* tmp, float* out, long n4) -> int {
+  auto reduce = [&](const float* in, float* tmp, float* out, long n4, int count) -> int {
     const unsigned gx = (unsigned)efm::cdiv(n4, 64);
-    if (pl.groups > 1) {
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, pl.groups), dim3(256), 0, s, in, tmp, n4, n4, pl.splits, pl.per_group, n4, 0);
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, pl.groups, pl.groups, n4, accumulate);
+    if (count > 32) {
+      const int groups = (count + 31) / 32;
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, in, tmp, n4, n4, count, 32, n4, 0);
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, groups, groups, n4, accumulate);
     } else {
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, pl.splits, pl.splits, n4, accumulate);
+      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, count, count, n4, accumulate);
     }
     return efm::check_launch("conv_wgrad_reduce");
   };
-  rc = reduce(slabs, lvl2, dw_packed, (long)d->n_pad16 * d->k_pad / 4);
+  rc = reduce(slabs, lvl2, dw_packed, (long)d->n_pad16 * d->k_pad / 4, pl.splits);
   if (rc != EFM_OK) return rc;
-  if (dbias) rc = reduce(bpart, bpart2, dbias, d->n_pad16 / 4);
+  if (dbias) rc = reduce(bpart, bpart2, dbias, d->n_pad16 / 4, pl.bias_chunks);
   return rc;
 }
 
