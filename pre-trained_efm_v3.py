@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's pre-trained_efm_v3.py: triplet-only fine-tuning of Dense(128, use_bias=False) on
+pre-extracted 342-d EFM features.
+
+    python pre-trained_efm_v3.py                     # reads train_img.csv, train_id.csv, test_img.csv, test_id.csv from CWD
+    python pre-trained_efm_v3.py --synthetic 65536   # splitmix64 features instead of the CSV files
+
+Same constants (feature_dim 342, batch 16384, SGD lr 2.4e-4 wd 1e-5, margin 0.5, 300 epochs; ref: :131-135,174-189), same
+loop (:193-221) and outputs (cosine_similarity.csv rows, fc_efm_res-%04d.params, the "Epoch N: train loss ..." line,
+:249-253).  The 16384-iteration Python negative loop with a device sync per sample (:202-207) is one vectorised draw
+plus one gather kernel; the 2*16384 cosine launches (:23-31) are one kernel.
+"""
+import argparse
+import csv
+import datetime
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from improving_face_recognition_performance_using_triplet_loss_amd import functional as F_
+from improving_face_recognition_performance_using_triplet_loss_amd.data import CSVIter, DataIter, define_pos, pick_negatives, synthetic_source
+from improving_face_recognition_performance_using_triplet_loss_amd.nn import Dense, Trainer, TripletLoss
+
+
+def ensure_dir(f):
+    d = os.path.dirname(f)
+    if d and not os.path.exists(d):
+        os.makedirs(d)
+
+
+def cosine_dist(anc, pos, neg, batch_size):
+    s_ap, s_an = F_.cosine_dist(anc[:batch_size], pos[:batch_size], neg[:batch_size])
+    return s_ap.cpu().tolist(), s_an.cpu().tolist()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--synthetic", type=int, default=0)
+    ap.add_argument("--epochs", type=int, default=300)
+    ap.add_argument("--batch-size", type=int, default=4096 * 4)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+    feature_dim, batch_size = 342, args.batch_size
+
+    if args.synthetic:
+        train_dataiter = synthetic_source(args.synthetic, (feature_dim,), max(args.synthetic // 8, 2), 1234, batch_size)
+        test_dataiter = synthetic_source(max(args.synthetic // 4, batch_size), (feature_dim,), max(args.synthetic // 32, 2), 4321, batch_size)
+        Training_IMG_number, Testing_IMG_number = args.synthetic, max(args.synthetic // 4, batch_size)
+    else:
+        with open("train_id.csv", "r") as file:
+            Training_IMG_number = len(file.readlines())
+        with open("test_id.csv", "r") as file:
+            Testing_IMG_number = len(file.readlines())
+        train_dataiter = CSVIter("train_img.csv", "train_id.csv", batch_size, feature_dim)
+        test_dataiter = CSVIter("test_img.csv", "test_id.csv", batch_size, feature_dim)
+    print("Totoal number of training samples = ", Training_IMG_number, flush=True)
+    print("Totoal number of testing samples = ", Testing_IMG_number, flush=True)
+    epoch_size = Training_IMG_number / batch_size
+    dshape = (batch_size, feature_dim)
+
+    Log_save_dir = "try2_efm_light_29/log/"
+    ensure_dir(Log_save_dir)
+    Model_save_name = "try2_efm_light_29"
+    logging.basicConfig(filename=Log_save_dir + Model_save_name + datetime.datetime.now().strftime("%Y-%m-%d_%H%M%S") + ".log", level=logging.INFO)
+
+    print("defining positive image...", flush=True)
+    pos_img_train = define_pos(train_dataiter, int(epoch_size), batch_size)
+    pos_img_test = define_pos(test_dataiter, int(Testing_IMG_number / batch_size), batch_size)
+    print("making training pairs...", flush=True)
+    data_train = DataIter(train_dataiter, int(epoch_size), pos_img_train, batch_size, dshape)
+    print("making testing pairs...", flush=True)
+    data_test = DataIter(test_dataiter, int(Testing_IMG_number / batch_size), pos_img_test, batch_size, dshape)
+
+    lr, MARGIN = 0.00024, 0.5
+    devs = torch.device("cuda", 0)
+    print("build network...", flush=True)
+    net = Dense(128, use_bias=False, in_units=feature_dim)
+    net._materialise(feature_dim, devs)
+    triplet_loss = TripletLoss(margin=MARGIN)
+    trainer = Trainer(net.parameters(), "sgd", learning_rate=lr, wd=0.00001)
+    rng = np.random.default_rng(args.seed)
+
+    def run(batch, train):
+        data = batch.data[0].to(devs)
+        label = batch.label[0].to(devs)
+        Wnx = net(data)
+        anc, pos = Wnx[0:batch_size], Wnx[batch_size:batch_size * 2]
+        pool = batch_size if train else batch_size * 2
+        neg = F_.gather_negatives(Wnx, pick_negatives(label, batch_size, pool, rng).to(devs))
+        return triplet_loss(anc, pos, neg), (anc, pos, neg)  # un-normalised Wnx, as the reference (:210)
+
+    print("start training...", flush=True)
+    for epoch in range(args.epochs):
+        train_loss, valid_loss = 0., 0.
+        tic = time.time()
+        for batch in data_train:
+            loss, (anc, pos, neg) = run(batch, True)
+            loss.sum().backward()
+            trainer.step(batch_size)
+            train_loss += loss.mean().item()
+            pos_dist, neg_dist = cosine_dist(anc, pos, neg, batch_size)
+            with open("cosine_similarity.csv", "a+", newline="") as csvfile:
+                csvwriter = csv.writer(csvfile, delimiter=" ")
+                for v in range(batch_size):
+                    csvwriter.writerow([pos_dist[v], neg_dist[v]])
+        with torch.no_grad():
+            for batch in data_test:
+                loss, _ = run(batch, False)
+                valid_loss += loss.mean().item()
+        paramfile = "fc_efm_res-%04d.params" % (epoch)
+        torch.save({"dense0_weight": net.weight_mx().cpu()}, paramfile)
+        print("Epoch {}: train loss {:g}, valid loss {:g}, in {:.1f} sec".format(
+            epoch, train_loss / epoch_size, valid_loss / (Testing_IMG_number / batch_size), time.time() - tic), flush=True)
+
+
+if __name__ == "__main__":
+    main()

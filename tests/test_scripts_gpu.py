@@ -1,0 +1,82 @@
+"""The drop-in entry points run end to end on the GPU (tiny synthetic configs) and keep the reference's observable outputs."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, args, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_train_efm_entry_point(tmp_path):
+    out = _run("train_efm.py", [str(tmp_path), "--synthetic", "32", "--epochs", "2", "--batch-size", "8", "--image-size", "32",
+                               "--classes", "16"], str(tmp_path))
+    lines = re.findall(r"Epoch (\d+): train loss ([\d.eE+-]+|nan), train acc ([\d.eE+-]+), valid loss ([\d.eE+-]+|nan), valid acc ([\d.eE+-]+), in ([\d.]+) sec", out)
+    assert [l[0] for l in lines] == ["0", "1"]
+    assert all(np.isfinite(float(l[1])) and np.isfinite(float(l[3])) for l in lines)
+    rows = open(tmp_path / "cosine_similarity.csv").read().strip().splitlines()
+    assert len(rows) == 2 * 4 * 8  # epochs x steps x batch rows, "s_ap s_an"
+    assert all(len(r.split(" ")) == 2 and -1.0001 <= float(r.split(" ")[0]) <= 1.0001 for r in rows)
+    assert (tmp_path / "efm_res-0000.params").exists() and (tmp_path / "efm_res-0001.params").exists()
+    assert os.listdir(tmp_path / "try2_efm_light_29_134" / "log")
+
+
+def test_pretrained_head_entry_point(tmp_path):
+    out = _run("pre-trained_efm_v3.py", ["--synthetic", "512", "--epochs", "3", "--batch-size", "64"], str(tmp_path))
+    losses = [float(v) for v in re.findall(r"Epoch \d+: train loss ([\d.eE+-]+), valid loss", out)]
+    assert len(losses) == 3 and all(np.isfinite(losses))
+    w = torch.load(tmp_path / "fc_efm_res-0002.params", weights_only=True)["dense0_weight"]
+    assert tuple(w.shape) == (128, 342)
+    assert len(open(tmp_path / "cosine_similarity.csv").read().strip().splitlines()) == 3 * 8 * 64
+
+
+def test_lightcnn29_forward_shapes_and_shared_weight_gradients():
+    """Gluon-variant network: (out, fc1_out) shapes, and the weight-sharing rule of its res_block (the same two
+    convolutions re-applied, ref: lightcnn.py:47-48,52-69): the gradient of a shared parameter equals the sum of the
+    gradients of the per-use copies of an otherwise identical network."""
+    import lightcnn
+    from improving_face_recognition_performance_using_triplet_loss_amd import graph as G
+    from improving_face_recognition_performance_using_triplet_loss_amd.nn import SymbolNet
+    net = lightcnn.LightCNN_29(10, in_channels=1, image=32)
+    out, fc = net(torch.rand(4, 1, 32, 32, device="cuda"))
+    assert tuple(out.shape) == (4, 10) and tuple(fc.shape) == (4, 684)
+
+    def build(shared):
+        x = G.Variable("data")
+        h = G.Convolution(x, 6, (3, 3), name="stem", pad=(1, 1))
+        if shared:
+            r = lightcnn.res_block(2, 9, "rb")(h)
+        else:
+            r = lightcnn.res_block(1, 9, "rb_a")(h)
+            r = lightcnn.res_block(1, 9, "rb_b")(r)
+        return [G.FullyConnected(G.Pooling(r), 5, name="fc")]
+
+    a = SymbolNet(build(True), 3, 8, seed=1)
+    b = SymbolNet(build(False), 3, 8, seed=2)
+    pa = {k: v.cpu().numpy() for k, v in a.export_params().items()}
+    pb = {}
+    for k in b.export_params():
+        pb[k] = pa[k.replace("rb_a", "rb").replace("rb_b", "rb")]
+    b.load_params(pb)
+    x = torch.rand(4, 3, 8, 8, device="cuda")
+    proj = torch.randn(4, 5, device="cuda")
+    for n in (a, b):
+        (n(x)[0] * proj).sum().backward()
+    ga = a.plan(4).export_params(a.flat.grad)
+    gb = b.plan(4).export_params(b.flat.grad)
+    assert torch.allclose(a(x)[0], b(x)[0], rtol=1e-6, atol=1e-7)
+    for k in ("rb_conv0_weight", "rb_conv0_bias", "rb_conv1_weight", "rb_conv1_bias"):
+        want = gb[k.replace("rb_", "rb_a_")] + gb[k.replace("rb_", "rb_b_")]
+        assert torch.allclose(ga[k], want, rtol=1e-4, atol=1e-6), k
+    assert torch.allclose(ga["stem_weight"], gb["stem_weight"], rtol=1e-4, atol=1e-6)
