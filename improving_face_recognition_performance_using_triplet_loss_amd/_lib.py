@@ -56,6 +56,7 @@ SIGNATURES = {
     "efm_triplet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "efm_triplet_bwd": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "efm_cosine_pairs": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "efm_pair_distance": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "efm_gram_cosine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "efm_mine_semihard": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "efm_sgd_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),

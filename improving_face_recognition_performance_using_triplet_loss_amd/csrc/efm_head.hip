@@ -169,6 +169,27 @@ __global__ void __launch_bounds__(256) cosine_pairs_k(const float* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(256) pair_distance_k(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ mean, float* __restrict__ sqdist,
+                                                       float* __restrict__ cosine, int rows, int d, int lda, int ldb) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* ar = a + (long)row * lda;
+  const float* br = b + (long)row * ldb;
+  float dd = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float mu = mean ? mean[k] : 0.f;
+    const float av = ar[k] - mu, bv = br[k] - mu;
+    const float df = av - bv;
+    dd = fmaf(df, df, dd); aa = fmaf(av, av, aa); bb = fmaf(bv, bv, bb); ab = fmaf(av, bv, ab);
+  }
+  dd = wave_sum(dd); aa = wave_sum(aa); bb = wave_sum(bb); ab = wave_sum(ab);
+  if (lane == 0) {
+    sqdist[row] = dd;
+    cosine[row] = ab / (sqrtf(aa) * sqrtf(bb));
+  }
+}
+
 // g[i][j] = <e_i, e_j> / (|e_i||e_j|).  Block = row i (4 waves), e_i staged in LDS; each wave walks
 // columns j = wave, wave+4, ...; a lane-strided dot + shuffle reduction per pair.
 __global__ void __launch_bounds__(256) gram_cosine_k(const float* __restrict__ e, float* __restrict__ g, int rows,
@@ -308,6 +329,13 @@ int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap
   EFM_REQUIRE(a && p && n && s_ap && s_an && rows > 0 && d > 0, "cosine_pairs: bad argument");
   hipLaunchKernelGGL(cosine_pairs_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, p, n, s_ap, s_an, rows, d, lda, ldp, ldn);
   return efm::check_launch("cosine_pairs");
+}
+
+int efm_pair_distance(const float* a, const float* b, const float* mean, float* sqdist, float* cosine, int rows, int d,
+                      int lda, int ldb, void* stream) {
+  EFM_REQUIRE(a && b && sqdist && cosine && rows > 0 && d > 0, "pair_distance: bad argument");
+  hipLaunchKernelGGL(pair_distance_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b, mean, sqdist, cosine, rows, d, lda, ldb);
+  return efm::check_launch("pair_distance");
 }
 
 int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream) {

@@ -257,6 +257,16 @@ def cosine_pairs(a, p, n):
     return s_ap, s_an
 
 
+def pair_distance(a, b, mean=None):
+    """-> (squared Euclidean distance, cosine similarity) per row, optionally after subtracting `mean` from both."""
+    _need_rows(a, b)
+    rows, d = a.shape
+    sq = torch.empty((rows,), dtype=torch.float32, device=a.device)
+    cs = torch.empty_like(sq)
+    check(_lib.load().efm_pair_distance(_p(a), _p(b), _p(mean), _p(sq), _p(cs), rows, d, _ld(a), _ld(b), _stream()), "efm_pair_distance")
+    return sq, cs
+
+
 def gram_cosine(e):
     _need_rows(e)
     rows, d = e.shape

@@ -147,6 +147,11 @@ int efm_triplet_bwd(const float* a, const float* p, const float* n, const float*
 /* s_ap[i] = cos(a_i,p_i), s_an[i] = cos(a_i,n_i) — cosine_dist (ref: train_efm.py:26-34). */
 int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap, float* s_an, int rows,
                      int d, int lda, int ldp, int ldn, void* stream);
+/* Verification-pair distances for the LFW protocol (ref: feature_extraction/facenet_version/facenet.py:412-426 `distance`):
+ * sqdist[i] = sum_d (a_i - b_i - (mean_a - mean_b))^2 ... with mean == NULL: sum_d (a_i - b_i)^2;
+ * cosine[i] = <a_i - mean, b_i - mean> / (|a_i - mean| |b_i - mean|).  `mean` is a [d] vector or NULL. */
+int efm_pair_distance(const float* a, const float* b, const float* mean, float* sqdist, float* cosine, int rows, int d,
+                      int lda, int ldb, void* stream);
 /* g[i][j] = cos(e_i, e_j): the batch-all-pairs cosine matrix (north_star mining path; no reference). */
 int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream);
 /* Semi-hard negative per (anchor i, positive pos[i]) from the cosine matrix g[rows][rows]:

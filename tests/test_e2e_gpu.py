@@ -162,3 +162,27 @@ def test_shard_sum_identity():
     total = shard_grads[0] + shard_grads[1]
     err = float((total - big.grad).abs().max() / big.grad.abs().max())
     assert err < 1e-4, err
+
+
+def test_mini_efm_vs_committed_golden():
+    """HIP path against the committed fixture tests/golden/mini_efm.npz (no oracle call at test time)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_mini_efm_golden as M
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mini_efm.npz"))
+    params, w_head, x, neg, demb = M.inputs()
+    tr = TripletTrainer(4, image=32)
+    allp = dict(params)
+    allp["head_weight"] = w_head
+    tr.plan.load_params(tr.flat, allp)
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), torch.as_tensor(neg).cuda())
+    assert rel_err(loss.cpu().numpy(), z["loss"]) < TOL
+    assert rel_err(tr.last["emb"].cpu().numpy(), z["emb"]) < TOL
+    assert rel_err(tr.last["feat"][:, :342].cpu().numpy(), z["feat"]) < TOL
+    tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
+    g = tr.plan.export_params(tr.grad)
+    assert rel_err(g["conv1_weight"].cpu().numpy(), z["grad_conv1_weight"]) < TOL
+    sums = np.array([float(g[k].abs().sum()) for k in sorted(k for k in g if k != "head_weight")])
+    assert np.abs(sums / z["grad_abs_sums"] - 1).max() < 5e-3

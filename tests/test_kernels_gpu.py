@@ -220,3 +220,15 @@ def test_optimisers(ops):
         ops.adam_update(wd_, dev(g), m, v, 2.4e-4, t, wd=1e-5, rescale=1.0 / 64)
         wr, mr, vr = O.adam_step(wr, g, mr, vr, t, 2.4e-4, 1e-5, 1.0 / 64)
     assert rel_err(wd_.cpu().numpy(), wr) < 1e-6
+
+
+@pytest.mark.parametrize("metric,sub", [(0, False), (0, True), (1, False), (1, True)])
+def test_lfw_evaluator_matches_reference_golden(ops, metric, sub):
+    """The device LFW evaluator against vectors produced by the reference's own calculate_roc."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import lfw
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lfw_roc.npz"))
+    key = "m%d_s%d" % (metric, int(sub))
+    tpr, fpr, acc = lfw.calculate_roc(z[key + "_thresholds"], dev(z["emb1"]), dev(z["emb2"]), z["issame"], 10, metric, sub)
+    # fp32 distances: a pair sitting within 1e-6 of a threshold may flip one count out of 60 per fold
+    assert np.abs(acc - z[key + "_acc"]).max() <= 1.0 / 60 + 1e-9 and abs(acc.mean() - z[key + "_acc"].mean()) < 2e-3
+    assert np.abs(tpr - z[key + "_tpr"]).max() < 5e-3 and np.abs(fpr - z[key + "_fpr"]).max() < 5e-3

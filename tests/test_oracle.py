@@ -204,3 +204,28 @@ def test_lfw_protocol_perfectly_separable(metric):
     e2 = np.where(same[:, None], near, -near)
     tpr, fpr, acc = O.lfw_roc(np.arange(0, 4, 0.01), e1, e2, same, nrof_folds=10, metric=metric)
     assert acc.mean() > 0.95 and tpr[-1] == 1.0 and fpr[0] == 0.0  # first-best-threshold rule can miss a test pair
+
+
+@pytest.mark.parametrize("metric,sub", [(0, False), (0, True), (1, False), (1, True)])
+def test_lfw_restatement_matches_reference_golden(metric, sub):
+    """Golden vectors produced by the reference's own calculate_roc (tests/golden/make_lfw_golden.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lfw_roc.npz"))
+    key = "m%d_s%d" % (metric, int(sub))
+    tpr, fpr, acc = O.lfw_roc(z[key + "_thresholds"], z["emb1"], z["emb2"], z["issame"], 10, metric, sub)
+    assert np.allclose(tpr, z[key + "_tpr"], atol=1e-12) and np.allclose(fpr, z[key + "_fpr"], atol=1e-12)
+    assert np.array_equal(acc, z[key + "_acc"])
+    assert 0.7 < acc.mean() < 0.99  # the fixture is neither trivial nor random
+
+
+def test_oracle_reproduces_mini_efm_golden():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_mini_efm_golden as M
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mini_efm.npz"))
+    params, w_head, x, neg, demb = M.inputs()
+    loss, emb, feat, grads, g_head = O.train_step_loss(params, w_head, x, neg, 0.2, demb=demb)
+    assert np.allclose(loss, z["loss"], rtol=1e-12) and np.allclose(emb, z["emb"], rtol=1e-10, atol=1e-14)
+    assert np.allclose(feat, z["feat"], rtol=1e-10, atol=1e-14)
+    assert np.allclose(np.array([np.abs(grads[k]).sum() for k in sorted(grads)]), z["grad_abs_sums"], rtol=1e-9)
