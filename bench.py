@@ -109,10 +109,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # rehearsal knobs (not used by the driver): all ranks on one device / gloo instead of RCCL, to exercise the
+    # multi-process path on a 1-GPU box
+    if os.environ.get("EFM_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("EFM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer

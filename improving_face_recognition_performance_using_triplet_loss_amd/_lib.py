@@ -42,6 +42,9 @@ SIGNATURES = {
     "efm_conv_unpack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "efm_conv_make_dgrad_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "efm_conv_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 6),
+    "efm_conv_mfm_supported": (c_int, [POINTER(ConvDesc)]),
+    "efm_conv_mfm_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "efm_mfm_pool_bwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "efm_conv_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
     "efm_conv_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "efm_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

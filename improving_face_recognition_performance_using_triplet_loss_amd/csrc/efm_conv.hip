@@ -39,6 +39,9 @@ struct ConvP {
   int nblocks;
   unsigned magic_c, magic_kw;  // ceil(2^32 / cin_p), ceil(2^32 / kw): exact k / cin_p and tap / kw for k < 2^16
   unsigned x_bytes, w_bytes;
+  // fused MFM (+ 2x2 max pooling) epilogue
+  unsigned char* route;  // per output element: slice (and window pixel) the value came from
+  int cout, ways, order, pool, hp, wp;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +53,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // K loop, so the compiler is free to schedule the loads among the MFMAs.
 // (The body lives in a __device__ function: the buffer-resource builtins only exist in the device pass, and a
 // __global__ template that names them directly loses its host-side launch stub.)
-template <int MT, int NT, bool DMA>
+template <int MT, int NT, bool DMA, int EPI>
 __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   constexpr int BM = MT * 64, BN = NT * 16;
   constexpr int PB = (NT * 64 + 255) / 256;
@@ -79,8 +82,23 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
     const int m = m0 + lrow + 64 * j;
     const bool ok = m < p.M;
     const int mm = ok ? m : 0;
-    const int b = mm / hw, r = mm - b * hw;
-    const int ho = r / p.wout, wo = r - ho * p.wout;
+    int b, ho, wo;
+    if (EPI == 1 && p.pool) {
+      // window-major pixel order: rows 4q..4q+3 are the 2x2 pooling window q = (b, hp, wp), scan order (dh, dw);
+      // in the MFMA result layout these are the 4 registers of one lane, so pooling needs no cross-lane traffic.
+      const int q = mm >> 2, jw = mm & 3;
+      const int hwp = p.hp * p.wp;
+      b = q / hwp;
+      const int r = q - b * hwp;
+      const int hq = r / p.wp, wq = r - hq * p.wp;
+      ho = 2 * hq + (jw >> 1);
+      wo = 2 * wq + (jw & 1);
+    } else {
+      b = mm / hw;
+      const int r = mm - b * hw;
+      ho = r / p.wout;
+      wo = r - ho * p.wout;
+    }
     a_hi0[j] = ok ? ho - p.pad_h : -(1 << 20);
     a_wi0[j] = wo - p.pad_w;
     a_base[j] = ((b * p.hin + ho - p.pad_h) * p.win + (wo - p.pad_w)) * p.cin_p;
@@ -178,22 +196,127 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
     __syncthreads();  // (with DMA in flight hipcc drains vmcnt(0) here: the next tile has landed)
   }
 
-  // ---- epilogue: D[row = 4*fq + r][col = fi] per 16x16 tile; + bias (+ residual)
+  if (EPI == 0) {
+    // ---- plain epilogue: D[row = 4*fq + r][col = fi] per 16x16 tile; + bias (+ residual)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + nt * 16 + fi;
-    if (n < p.cout_p) {
-      const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + nt * 16 + fi;
+      if (n < p.cout_p) {
+        const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wave * (MT * 16) + mt * 16 + fq * 4 + r;
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wave * (MT * 16) + mt * 16 + fq * 4 + r;
+            if (m < p.M) {
+              const long off = (long)m * p.cout_p + n;
+              float v = acc[mt][nt][r] + bv;
+              if (p.res) v += p.res[off];
+              p.y[off] = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- fused epilogue: + bias -> MFM (max / min feature map across channel slices) -> optional 2x2 max pooling.
+  // The slices of one channel sit in different lanes, so each wave transposes R result rows through its own LDS
+  // region [row][channel] and re-reads them with lane = channel; pooling windows are 4 consecutive rows.
+  constexpr int R = (NT <= 8) ? 16 : 8;
+  constexpr int ES = BN + 4;
+  float* Es = smem + wave * (R * ES);
+  const int ways = p.ways, cs = p.cout / ways;
+  const int co = (ways == 3) ? 2 * cs : cs;   // real output channels
+  const int cpo = (co + 3) & ~3;              // channel stride of z and of the route bytes
+  auto slice3 = [&](float x0, float x1, float x2, float& vmax, int& imax, float& vmin, int& imin) {
+    // MXNet: maximum/minimum(lhs, rhs) backward sends a tie to lhs; ORDER_GROUP = max(max(s0,s1),s2), ORDER_RES = max(s2, max(s0,s1))
+    imax = (x0 >= x1) ? 0 : 1;
+    imin = (x0 <= x1) ? 0 : 1;
+    const float m1 = fmaxf(x0, x1), n1 = fminf(x0, x1);
+    if (p.order == EFM_MFM_ORDER_GROUP) {
+      if (!(m1 >= x2)) imax = 2;
+      if (!(n1 <= x2)) imin = 2;
+    } else {
+      if (x2 >= m1) imax = 2;
+      if (x2 <= n1) imin = 2;
+    }
+    vmax = fmaxf(m1, x2);
+    vmin = fminf(n1, x2);
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int h = 0; h < 16 / R; ++h) {
+      __syncthreads();  // LDS free: K-loop reads / previous pass reads are done
+      if (R == 16 || (fq >> 1) == h) {
+        const int rr = (R == 16) ? 4 * fq : 4 * (fq & 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = nt * 16 + fi;
+          const float bv = (p.bias && n < p.n_pad16) ? p.bias[n] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Es[(rr + r) * ES + n] = acc[mt][nt][r] + bv;
+        }
+      }
+      __syncthreads();
+      const int row0 = m0 + wave * (MT * 16) + mt * 16 + h * R;  // first result row of this pass
+      if (p.pool) {
+#pragma unroll
+        for (int wnd = 0; wnd < R / 4; ++wnd) {
+          const int m = row0 + 4 * wnd;
           if (m < p.M) {
-            const long off = (long)m * p.cout_p + n;
-            float v = acc[mt][nt][r] + bv;
-            if (p.res) v += p.res[off];
-            p.y[off] = v;
+            const long q = m >> 2;  // pooled output pixel (b, hp, wp), linear
+            for (int c = lane; c < cs; c += 64) {
+              float bmax = 0.f, bmin = 0.f;
+              int rmax = 0, rmin = 0;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float* e = Es + (4 * wnd + j) * ES;
+                float vmax, vmin = 0.f;
+                int imax, imin = 0;
+                if (ways == 3) {
+                  slice3(e[c], e[cs + c], e[2 * cs + c], vmax, imax, vmin, imin);
+                } else {
+                  const float x0 = e[c], x1 = e[cs + c];
+                  imax = (x0 >= x1) ? 0 : 1;
+                  vmax = fmaxf(x0, x1);
+                }
+                if (j == 0 || vmax > bmax) { bmax = vmax; rmax = j * 4 + imax; }   // first maximum of the window wins
+                if (j == 0 || vmin > bmin) { bmin = vmin; rmin = j * 4 + imin; }
+              }
+              p.y[q * cpo + c] = bmax;
+              p.route[q * cpo + c] = (unsigned char)rmax;
+              if (ways == 3) {
+                p.y[q * cpo + cs + c] = bmin;
+                p.route[q * cpo + cs + c] = (unsigned char)rmin;
+              }
+            }
+            if (lane < cpo - co) p.y[q * cpo + co + lane] = 0.f;
+          }
+        }
+      } else {
+        for (int row = 0; row < R; ++row) {
+          const long m = row0 + row;
+          if (m < p.M) {
+            const float* e = Es + row * ES;
+            for (int c = lane; c < cs; c += 64) {
+              if (ways == 3) {
+                float vmax, vmin;
+                int imax, imin;
+                slice3(e[c], e[cs + c], e[2 * cs + c], vmax, imax, vmin, imin);
+                p.y[m * cpo + c] = vmax;
+                p.y[m * cpo + cs + c] = vmin;
+                p.route[m * cpo + c] = (unsigned char)imax;
+                p.route[m * cpo + cs + c] = (unsigned char)imin;
+              } else {
+                const float x0 = e[c], x1 = e[cs + c];
+                p.y[m * cpo + c] = fmaxf(x0, x1);
+                p.route[m * cpo + c] = (unsigned char)((x0 >= x1) ? 0 : 1);
+              }
+            }
+            if (lane < cpo - co) p.y[m * cpo + co + lane] = 0.f;
           }
         }
       }
@@ -201,11 +324,79 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   }
 }
 
-template <int MT, int NT, bool DMA>
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int MT, int NT, bool DMA, int EPI>
 __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (MT * 64 + NT * 16) * 16];
-  conv_fwd_body<MT, NT, DMA>(p, smem);
+  // K-loop double buffer, re-used by the fused epilogue as 4 per-wave transposition regions of R rows x (BN + 4)
+  __shared__ __attribute__((aligned(16))) float smem[cmax(2 * (MT * 64 + NT * 16) * 16,
+                                                            EPI ? 4 * ((NT <= 8) ? 16 : 8) * (NT * 16 + 4) : 0)];
+  conv_fwd_body<MT, NT, DMA, EPI>(p, smem);
 }
+
+// Backward of the fused MFM (+ pooling) epilogue: scatters dz to the conv-output positions recorded in `route` and
+// writes EVERY element of dy (zeros elsewhere, pad channels, and the odd trailing row / column that floor pooling drops).
+// thread = (window or pixel, channel j); j < cs + pad channels.
+__global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __restrict__ route, const float* __restrict__ dz,
+                                                      float* __restrict__ dy, long items, int h, int w, int c, int ways,
+                                                      int pool, int cw) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= items * cw) return;
+  const long it = i / cw;
+  const int j = (int)(i - it * cw);
+  const int cs = c / ways, cp = (c + 3) & ~3;
+  const int co = (ways == 3) ? 2 * cs : cs, cpo = (co + 3) & ~3;
+  if (!pool) {
+    float* d = dy + it * cp;
+    if (j < cs) {
+      const float gmax = dz[it * cpo + j];
+      const int imax = route[it * cpo + j];
+      float o0 = imax == 0 ? gmax : 0.f, o1 = imax == 1 ? gmax : 0.f, o2 = imax == 2 ? gmax : 0.f;
+      if (ways == 3) {
+        const float gmin = dz[it * cpo + cs + j];
+        const int imin = route[it * cpo + cs + j];
+        o0 += imin == 0 ? gmin : 0.f; o1 += imin == 1 ? gmin : 0.f; o2 += imin == 2 ? gmin : 0.f;
+        d[2 * cs + j] = o2;
+      }
+      d[j] = o0; d[cs + j] = o1;
+    } else if (c + (j - cs) < cp) {
+      d[c + (j - cs)] = 0.f;
+    }
+    return;
+  }
+  // pooled: item = window of the ceil grid (partial windows at odd edges only write zeros)
+  const int hg = (h + 1) >> 1, wg = (w + 1) >> 1, hp = h >> 1, wp = w >> 1;
+  const int wq = (int)(it % wg);
+  const long t = it / wg;
+  const int hq = (int)(t % hg);
+  const long b = t / hg;
+  const bool full = hq < hp && wq < wp;
+  float gmax = 0.f, gmin = 0.f;
+  int rmax = -1, rmin = -1;
+  if (full && j < cs) {
+    const long q = (b * hp + hq) * wp + wq;
+    gmax = dz[q * cpo + j];
+    rmax = route[q * cpo + j];
+    if (ways == 3) { gmin = dz[q * cpo + cs + j]; rmin = route[q * cpo + cs + j]; }
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    const int hh = 2 * hq + (px >> 1), ww = 2 * wq + (px & 1);
+    if (hh >= h || ww >= w) continue;
+    float* d = dy + ((b * h + hh) * w + ww) * cp;
+    if (j < cs) {
+      for (int sl = 0; sl < ways; ++sl) {
+        float o = (rmax == px * 4 + sl) ? gmax : 0.f;
+        if (ways == 3 && rmin == px * 4 + sl) o += gmin;
+        d[sl * cs + j] = o;
+      }
+    } else if (c + (j - cs) < cp) {
+      d[c + (j - cs)] = 0.f;
+    }
+  }
+}
+
+
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient.  C[n][k] = sum_m dy[m][n] * A[m][k].  MFMA A operand = dy (rows = n),
@@ -488,13 +679,34 @@ int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<MT, N, DMA>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<MT, N, DMA, 0>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
 #undef EFM_CASE
   }
   efm::set_error("conv_fwd: unsupported NT=%d", NT);
   return EFM_E_INVALID;
+}
+
+// fused-epilogue variants: one channel block holds every slice of a channel, 64-row tiles
+int launch_fwd_epi(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
+  switch (NT) {
+#define EFM_CASE(N)                                          \
+  case N:                                                    \
+    hipLaunchKernelGGL((conv_fwd_k<1, N, true, 1>), grid, dim3(256), 0, s, p); \
+    return EFM_OK;
+    EFM_CASE(3) EFM_CASE(5) EFM_CASE(7) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13) EFM_CASE(17) EFM_CASE(25)
+#undef EFM_CASE
+  }
+  efm::set_error("conv_mfm_fwd: unsupported NT=%d", NT);
+  return EFM_E_INVALID;
+}
+
+int round_nt_epi(int nt) {
+  static const int ok[] = {3, 5, 7, 9, 11, 13, 17, 25};
+  for (int v : ok)
+    if (v >= nt) return v;
+  return -1;
 }
 
 int round_nt(int nt) {
@@ -515,6 +727,7 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   p.hout = hout; p.wout = wout; p.cout_p = cout_p;
   p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
   p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
+  p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0;
   const int tiles = n_pad16 / 16;
   const int nblocks = (tiles + 12) / 13;
   const int NT = round_nt((tiles + nblocks - 1) / nblocks);
@@ -649,6 +862,47 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
   EFM_REQUIRE(d && x && w_packed && y, "conv_fwd: null argument");
   return run_fwd(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
                  d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, (hipStream_t)stream);
+}
+
+int efm_conv_mfm_supported(const efm_conv_desc* d) { return d && round_nt_epi(d->n_pad16 / 16) > 0; }
+
+int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
+                     unsigned char* route, int ways, int order, int pool, void* stream) {
+  EFM_REQUIRE(d && x && w_packed && z && route, "conv_mfm_fwd: null argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
+  EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
+  const int NT = round_nt_epi(d->n_pad16 / 16);
+  EFM_REQUIRE(NT > 0, "conv_mfm_fwd: %d output channels exceed one channel block", d->cout);
+  ConvP p;
+  p.x = x; p.w = w_packed; p.bias = bias; p.res = nullptr; p.y = z;
+  p.hin = d->hin; p.win = d->win; p.cin_p = d->cin_p;
+  p.hout = d->hout; p.wout = d->wout; p.cout_p = d->cout_p;
+  p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad; p.ksteps = d->k_pad / 16;
+  p.nblocks = 1;
+  p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
+  p.hp = d->hout / 2; p.wp = d->wout / 2;
+  p.M = pool ? d->batch * p.hp * p.wp * 4 : d->batch * d->hout * d->wout;
+  p.magic_c = (unsigned)((0x100000000ULL + (unsigned)d->cin_p - 1) / (unsigned)d->cin_p);
+  p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)d->kw - 1) / (unsigned)d->kw);
+  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
+  p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
+  dim3 grid((unsigned)efm::cdiv(p.M, 64));
+  int rc = launch_fwd_epi(NT, grid, (hipStream_t)stream, p);
+  if (rc != EFM_OK) return rc;
+  return efm::check_launch("conv_mfm_fwd");
+}
+
+int efm_mfm_pool_bwd(const unsigned char* route, const float* dz, float* dy, int batch, int h, int w, int c, int ways,
+                     int pool, void* stream) {
+  EFM_REQUIRE(route && dz && dy && batch > 0 && h > 0 && w > 0, "mfm_pool_bwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfm_pool_bwd: c=%d not divisible by ways=%d", c, ways);
+  const int cs = c / ways, cw = cs + (efm_pad4(c) - c);
+  const long items = pool ? (long)batch * ((h + 1) / 2) * ((w + 1) / 2) : (long)batch * h * w;
+  hipLaunchKernelGGL(mfm_pool_bwd_k, dim3((unsigned)efm::cdiv(items * cw, 256)), dim3(256), 0, (hipStream_t)stream, route, dz, dy,
+                     items, h, w, c, ways, pool ? 1 : 0, cw);
+  return efm::check_launch("mfm_pool_bwd");
 }
 
 int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed, const float* add,

@@ -89,6 +89,32 @@ def conv_fwd(d, x, wp, bias=None, residual=None, out=None):
     return out
 
 
+def conv_mfm_supported(d):
+    return bool(_lib.load().efm_conv_mfm_supported(ctypes.byref(d)))
+
+
+def conv_mfm_fwd(d, x, wp, bias, ways=3, order=_lib.MFM_ORDER_GROUP, pool=False):
+    """Fused conv + bias + MFM (+ 2x2 max pooling): returns (z, route)."""
+    _need_dev(x, wp, bias)
+    assert x.numel() == d.batch * d.hin * d.win * d.cin_p and wp.numel() == d.n_pad16 * d.k_pad
+    co = pad4(mfm_out_channels(d.cout, ways))
+    ho, wo = (d.hout // 2, d.wout // 2) if pool else (d.hout, d.wout)
+    z = torch.empty((d.batch, ho, wo, co), dtype=torch.float32, device=x.device)
+    route = torch.empty((d.batch, ho, wo, co), dtype=torch.uint8, device=x.device)
+    check(_lib.load().efm_conv_mfm_fwd(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(z), ctypes.c_void_p(route.data_ptr()),
+                                       ways, order, int(bool(pool)), _stream()), "efm_conv_mfm_fwd")
+    return z, route
+
+
+def mfm_pool_bwd(d, route, dz, ways=3, pool=False):
+    """Gradient of the fused epilogue w.r.t. the (never materialised) conv output: (B, hout, wout, cout_p)."""
+    _need_dev(dz)
+    dy = torch.empty((d.batch, d.hout, d.wout, d.cout_p), dtype=torch.float32, device=dz.device)
+    check(_lib.load().efm_mfm_pool_bwd(ctypes.c_void_p(route.data_ptr()), _p(dz), _p(dy), d.batch, d.hout, d.wout, d.cout, ways,
+                                       int(bool(pool)), _stream()), "efm_mfm_pool_bwd")
+    return dy
+
+
 def conv_bwd_data(d, dy, wd, add=None, out=None):
     _need_dev(dy, wd, add, out)
     if out is None:

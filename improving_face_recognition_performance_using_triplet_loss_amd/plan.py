@@ -11,6 +11,7 @@ train_efm.py:209) plays for the reference, designed for one MI355X per process:
     gradient is final, so the all-reduce of late layers overlaps the backward of early ones.
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -36,6 +37,7 @@ class Step:
         self.inputs = inputs        # producer steps
         self.shape = shape          # (C, H, W) of the output
         self.residual = None        # conv only: step whose output is added in the epilogue
+        self.epi = None             # conv only: fused MFM (+ pool) epilogue {ways, order, pool, conv_shape}
         self.desc = None
         self.pname = None
         self.no_bias = False
@@ -44,13 +46,19 @@ class Step:
 
 
 class Plan:
-    def __init__(self, outputs, input_shape, device="cuda"):
+    def __init__(self, outputs, input_shape, device="cuda", fuse=None):
+        """fuse: fold `conv -> MFM [-> pool]` chains into the convolution's epilogue (default on; EFM_FUSE=0 or
+        fuse=False keeps one kernel per graph node — the form the oracle-routing parity test uses)."""
         self.device = torch.device(device)
         self.batch = int(input_shape[0])
         self.input_shape = tuple(int(v) for v in input_shape)
         self.steps = []
         self.params = collections.OrderedDict()
         self._lower(outputs)
+        self.fuse = (os.environ.get("EFM_FUSE", "1") != "0") if fuse is None else bool(fuse)
+        self.fused = 0
+        if self.fuse:
+            self._fuse()
         self._acts = None
         self._views = {}
         self._wd_scratch = None
@@ -148,6 +156,49 @@ class Plan:
         self.flops_fwd = sum(2 * s.desc.batch * s.desc.hout * s.desc.wout * s.desc.cout * s.desc.cin * s.desc.kh * s.desc.kw
                              for s in self.steps if s.op == "conv")
 
+    def _fuse(self):
+        """conv -> MFM [-> pool 2x2] with single consumers becomes ONE step (the fused epilogue of efm_conv_mfm_fwd)."""
+        users = collections.defaultdict(list)
+        for st in self.steps:
+            for i in st.inputs:
+                users[i.index].append(st)
+            if st.residual is not None:
+                users[st.residual.index].append(st)
+        out_idx = {st.index for st in self.outputs}
+        dead, remap = set(), {}
+        for m in self.steps:
+            if m.op != "mfm":
+                continue
+            s = m.inputs[0]
+            if s.op != "conv" or s.residual is not None or s.index in out_idx or users[s.index] != [m]:
+                continue
+            if getattr(s, "epi", None) is not None or not ops.conv_mfm_supported(s.desc):
+                continue
+            pool = None
+            if m.index not in out_idx and len(users[m.index]) == 1 and users[m.index][0].op == "pool" \
+                    and users[m.index][0].inputs[0] is m:
+                pool = users[m.index][0]
+            s.epi = {"ways": m.node.attrs["ways"], "order": m.node.attrs["order"], "pool": pool is not None,
+                     "conv_shape": s.shape, "names": [m.node.name] + ([pool.node.name] if pool else [])}
+            last = pool if pool is not None else m
+            s.shape = last.shape
+            dead.add(m.index)
+            remap[m.index] = s
+            if pool is not None:
+                dead.add(pool.index)
+                remap[pool.index] = s
+            self.fused += 1
+        if not dead:
+            return
+        for st in self.steps:
+            st.inputs = [remap.get(i.index, i) for i in st.inputs]
+            if st.residual is not None:
+                st.residual = remap.get(st.residual.index, st.residual)
+        self.outputs = [remap.get(o.index, o) for o in self.outputs]
+        self.steps = [st for st in self.steps if st.index not in dead]
+        for k, st in enumerate(self.steps):
+            st.index = k
+
     # --------------------------------------------------------------------------- parameters
     def new_flat(self):
         return torch.zeros(self.num_flat, dtype=torch.float32, device=self.device)
@@ -226,6 +277,10 @@ class Plan:
             elif st.op == "conv":
                 w = v[st.pname + "_weight"]
                 bias = None if st.no_bias else v[st.pname + "_bias"]
+                if st.epi is not None:
+                    acts[st.index], aux[st.index] = ops.conv_mfm_fwd(st.desc, acts[st.inputs[0].index], w, bias, st.epi["ways"],
+                                                                     st.epi["order"], st.epi["pool"])
+                    continue
                 res = acts[st.residual.index] if st.residual is not None else None
                 acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
             elif st.op == "mfm":
@@ -279,6 +334,8 @@ class Plan:
             if st.op == "conv":
                 d = st.desc
                 src = st.inputs[0]
+                if st.epi is not None:  # gradient of the fused MFM (+ pool) epilogue -> full conv-output gradient
+                    dy = ops.mfm_pool_bwd(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
                 wname = st.pname + "_weight"
                 acc = wname in written
                 ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
@@ -326,6 +383,9 @@ class Plan:
     def routing_inputs(self):
         """{MFM / pooling node name -> its INPUT activation as an NCHW torch tensor} of the last forward(train=True);
         lets a higher-precision checker follow the same arg-max routes (tests only)."""
+        if self.fused:
+            raise RuntimeError("routing_inputs() needs an unfused plan (Plan(..., fuse=False)): fused epilogues never "
+                               "materialise the MFM inputs")
         out = {}
         for st in self.steps:
             if st.op in ("mfm", "pool"):

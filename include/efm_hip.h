@@ -95,6 +95,19 @@ int efm_conv_make_dgrad_weights(const efm_conv_desc* d, const float* w_packed, f
  * (ref: efm_symbol.py:42 `data + conv_r1`). */
 int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                  const float* residual, float* y, void* stream);
+/* Fused forward: z = [maxpool2x2(] MFM(conv(x, w) + bias) [)] in ONE launch — the conv result never reaches HBM.
+ * Replaces the Convolution -> SliceChannel/maximum/minimum/Concat [-> Pooling] chains of group()/res_block()
+ * (ref: efm_symbol.py:32-39, 54-60, 65-78).  z: [batch][h'][w'][pad4(c')] with c' = 2*cout/3 (ways 3) or cout/2 (ways 2)
+ * and (h', w') = (hout/2, wout/2) when pool else (hout, wout).  route: one byte per element of z (same shape) recording the
+ * slice (and, with pooling, the window pixel: 4*pixel + slice) the value came from, with MXNet's tie rules.
+ * Needs every slice of a channel in one channel block: efm_conv_mfm_supported(d) != 0  (cout <= 400). */
+int efm_conv_mfm_supported(const efm_conv_desc* d);
+int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
+                     unsigned char* route, int ways, int order, int pool, void* stream);
+/* Backward of that epilogue: dy[batch][h][w][pad4(c)] (the full conv-output gradient, every element written) from dz and
+ * route; (h, w, c) are the conv OUTPUT dims. */
+int efm_mfm_pool_bwd(const unsigned char* route, const float* dz, float* dy, int batch, int h, int w, int c, int ways,
+                     int pool, void* stream);
 /* dx = conv_transpose(dy, w) (+ add).  `add` has dx's shape or NULL (skip-path gradient). */
 int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed,
                       const float* add, float* dx, void* stream);

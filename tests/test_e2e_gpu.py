@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _make(batch, image, seed=1234):
+def _make(batch, image, seed=1234, fuse=None):
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
     shapes = O.efm29_param_shapes(3, image)
     params = O.init_params(shapes, 42)
     w_head = O.uniform_pm((128, 342), 777, O.xavier_uniform_scale((128, 342)))
     x = O.uniform01(batch * 3 * image * image, seed).reshape(batch, 3, image, image)
-    tr = TripletTrainer(batch, image=image, optimizer="sgd", lr=0.05, wd=1e-5)
+    tr = TripletTrainer(batch, image=image, optimizer="sgd", lr=0.05, wd=1e-5, fuse=fuse)
     allp = dict(params)
     allp["head_weight"] = w_head
     tr.plan.load_params(tr.flat, allp)
@@ -87,7 +87,7 @@ def test_112_step_vs_oracles():
     forward (`routing=`): those gradients are piecewise constant in the forward values, and a last-bit difference
     between two correct forwards flips a few routes — the SAME oracle run in fp32 on the CPU differs from its own
     fp64 run by ~6e-3 on these inputs (asserted below as the noise floor that makes the routing hand-over necessary)."""
-    tr, params, w_head, x = _make(8, 112)
+    tr, params, w_head, x = _make(8, 112, fuse=False)  # one kernel per graph node: the MFM inputs exist for the route hand-over
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     labels = synth.parity_labels(8, images_per_identity=2)
     neg = synth.negative_indices(labels, 99)
@@ -186,3 +186,20 @@ def test_mini_efm_vs_committed_golden():
     assert rel_err(g["conv1_weight"].cpu().numpy(), z["grad_conv1_weight"]) < TOL
     sums = np.array([float(g[k].abs().sum()) for k in sorted(k for k in g if k != "head_weight")])
     assert np.abs(sums / z["grad_abs_sums"] - 1).max() < 5e-3
+
+
+def test_fused_plan_is_bitwise_equal_to_unfused():
+    """The fused conv+MFM(+pool) epilogues change where bytes travel, not a single bit of the result: loss, embeddings
+    and the whole flat gradient of a step are identical with fuse=True / fuse=False (3x112x112: includes 7 -> 3 pooling)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    res = []
+    for fuse in (True, False):
+        tr = TripletTrainer(8, image=112, seed=5, fuse=fuse)
+        assert (tr.plan.fused == 19) if fuse else (tr.plan.fused == 0)
+        x = synth.images(8, 3, 112, 21)
+        neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 9).cuda()
+        loss = tr.forward_loss(x, neg).clone()
+        tr.backward()
+        res.append((loss, tr.last["emb"].clone(), tr.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*res))

@@ -232,3 +232,53 @@ def test_lfw_evaluator_matches_reference_golden(ops, metric, sub):
     # fp32 distances: a pair sitting within 1e-6 of a threshold may flip one count out of 60 per fold
     assert np.abs(acc - z[key + "_acc"]).max() <= 1.0 / 60 + 1e-9 and abs(acc.mean() - z[key + "_acc"].mean()) < 2e-3
     assert np.abs(tpr - z[key + "_tpr"]).max() < 5e-3 and np.abs(fpr - z[key + "_fpr"]).max() < 5e-3
+
+
+FUSED_CASES = [
+    # batch, h, w, cin, cout, k, pad, ways, pool
+    (2, 12, 10, 3, 99, 5, 2, 3, True),     # conv1-like -> MFM3 -> pool
+    (3, 8, 8, 66, 198, 3, 1, 3, True),     # conv2-like, NT = 13
+    (2, 7, 7, 174, 261, 3, 1, 3, True),    # odd map: 7 -> 3 (floor), NT = 17
+    (2, 6, 6, 132, 387, 3, 1, 3, True),    # NT = 25
+    (2, 9, 11, 44, 99, 3, 1, 3, False),    # conv_res -> MFM3 (no pooling)
+    (2, 5, 5, 258, 387, 1, 0, 3, False),   # conv_r 1x1
+    (2, 10, 8, 3, 96, 5, 2, 2, True),      # LightCNN-style MFM2 + pool
+    (1, 6, 6, 48, 80, 3, 1, 2, False),     # MFM2, NT rounds 5 -> 5
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_conv_mfm_pool_fused(ops, case):
+    """Fused conv + bias + MFM (+ pool) against the oracle chain, and BITWISE against the unfused kernels (same MFMA
+    order per pixel, same tie rules), forward and backward."""
+    b, h, w, cin, cout, k, pad, ways, pool = case
+    x = rand((b, cin, h, w), 31)
+    wt = rand((cout, cin, k, k), 32, 0.2)
+    bias = rand((cout,), 33)
+    d = ops.conv_desc(b, h, w, cin, cout, k, k, pad, pad)
+    assert ops.conv_mfm_supported(d)
+    xd = to_nhwc(x)
+    wp = ops.conv_pack_weights(d, dev(wt))
+    bp = torch.zeros(d.n_pad16, device="cuda")
+    bp[:cout] = dev(bias)
+    y_ref = O.conv2d(x, wt, bias, (pad, pad))
+    z_ref = O.mfm3(y_ref) if ways == 3 else O.mfm2(y_ref)
+    if pool:
+        z_ref = O.maxpool2(z_ref)
+    co = z_ref.shape[1]
+    for order in (O.ORDER_GROUP, O.ORDER_RES):
+        z, route = ops.conv_mfm_fwd(d, xd, wp, bp, ways, order, pool)
+        assert rel_err(from_nhwc(z, co), z_ref) < TOL
+        # unfused chain on the device
+        y = ops.conv_fwd(d, xd, wp, bp)
+        mf = ops.mfm_fwd(y, cout, ways)
+        zu = ops.maxpool2_fwd(mf, co) if pool else mf
+        assert torch.equal(z, zu)
+        dz = rand(z_ref.shape, 34)
+        dzd = to_nhwc(dz)
+        dy = torch.full((b, h, w, d.cout_p), float("nan"), device="cuda")
+        dyf = ops.mfm_pool_bwd(d, route, dzd, ways, pool)
+        dmf = ops.maxpool2_bwd(mf, dzd, co) if pool else dzd
+        dyu = ops.mfm_bwd(y, dmf, cout, ways, order)
+        assert torch.equal(dyf, dyu)
+        assert not torch.isnan(dyf).any() and dy.shape == dyf.shape
