@@ -39,6 +39,8 @@ def workspace(nbytes, device):
     key = (device.type, device.index)
     ws = _workspace.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            torch.cuda.synchronize(device)  # kernels on any stream may still use the old buffer (first steps only)
         ws = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
         _workspace[key] = ws
     return ws

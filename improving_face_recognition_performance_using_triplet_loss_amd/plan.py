@@ -62,6 +62,8 @@ class Plan:
         self._acts = None
         self._views = {}
         self._wd_scratch = None
+        self._side = None
+        self.two_streams = os.environ.get("EFM_TWO_STREAMS", "1") != "0"
 
     # ------------------------------------------------------------------------------ lowering
     def _lower(self, outputs):
@@ -324,6 +326,10 @@ class Plan:
             gr[st.index] = g
         written = set()
         remaining = dict(self._use_count)
+        # Weight gradient and data gradient of a layer both consume dy and are independent: the weight gradients run on
+        # a second HIP stream so that each kernel's last, partially filled round of blocks is covered by the other's.
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        side = self._side_stream() if (main is not None and self.two_streams) else None
         if self.max_dgrad_elems and (self._wd_scratch is None or self._wd_scratch.numel() < self.max_dgrad_elems):
             self._wd_scratch = torch.empty(self.max_dgrad_elems, dtype=torch.float32, device=self.device)
         dx_input = None
@@ -338,8 +344,15 @@ class Plan:
                     dy = ops.mfm_pool_bwd(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
                 wname = st.pname + "_weight"
                 acc = wname in written
-                ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
-                                    want_bias=not st.no_bias, accumulate=acc)
+                if side is not None:
+                    side.wait_stream(main)
+                    dy.record_stream(side)
+                    with torch.cuda.stream(side):
+                        ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
+                                            want_bias=not st.no_bias, accumulate=acc)
+                else:
+                    ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
+                                        want_bias=not st.no_bias, accumulate=acc)
                 written.add(wname)
                 if st.residual is not None:
                     r = st.residual.index
@@ -355,7 +368,11 @@ class Plan:
                 if ready_cb is not None and remaining[wname] == 0:
                     ps = self.params[wname]
                     hi = ps.offset + ps.numel + (0 if st.no_bias else d.n_pad16)
-                    ready_cb(ps.offset, hi)
+                    if side is not None:
+                        with torch.cuda.stream(side):  # the collective must order after the weight-gradient stream
+                            ready_cb(ps.offset, hi)
+                    else:
+                        ready_cb(ps.offset, hi)
             elif st.op == "mfm":
                 src = st.inputs[0]
                 prev = gr.pop(src.index, None)
@@ -378,7 +395,14 @@ class Plan:
                 gr[src.index] = dx
             elif st.op == "input":
                 dx_input = dy
+        if side is not None:
+            main.wait_stream(side)
         return dx_input
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def routing_inputs(self):
         """{MFM / pooling node name -> its INPUT activation as an NCHW torch tensor} of the last forward(train=True);

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     a = ap.parse_args()
-    plan = Plan(efm_symbol.embedding_net(), (a.batch, 3, a.image, a.image))
+    plan = Plan(efm_symbol.embedding_net(), (a.batch, 3, a.image, a.image), fuse=True)
     want = set(a.layers.split(",")) if a.layers else None
     what = a.what.split(",")
     tot = {k: 0.0 for k in what}
@@ -67,6 +67,9 @@ def main():
                 continue
             if k == "fwd":
                 ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
+                if st.epi is not None:
+                    ms2 = timeit(lambda: ops.conv_mfm_fwd(d, x, w, b, st.epi["ways"], st.epi["order"], st.epi["pool"]), a.iters)
+                    line += "  fused %7.3f ms %6.1f TF |" % (ms2, flops / ms2 / 1e9)
             elif k == "dgrad":
                 ms = timeit(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), a.iters)
             else:
