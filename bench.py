@@ -22,6 +22,13 @@ FLOP_PER_IMAGE_STEP = 15256522908  # SURVEY.md §8d / BASELINE.md §2: 3*fwd - d
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
+def baseline_metric():
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "triplets/sec (whole node) EFM 112x112 bs256/GPU at 1/2/4/8 MI355X; LFW acc"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,9 +63,14 @@ def dominant_kernel_roofline(trainer, torch, iters=5):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_fwd_k<2,13> (conv2 forward, 66->198 3x3 @56x56, B=%d)" % d.batch,
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))["traffic"]
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "conv_fwd_k<1,13,dma,plain> (conv2 forward, 66->198 3x3 @56x56, B=%d)" % d.batch,
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
@@ -116,7 +128,12 @@ def main():
     backend = os.environ.get("EFM_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("EFM_FORCE_ALLREDUCE"):
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -125,7 +142,8 @@ def main():
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
 
-    tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42)
+    tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
+                        n_buckets=int(os.environ.get("EFM_BUCKETS", "6")))
     labels = synth.parity_labels(args.batch, rank=rank)
     batches = []
     for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step
@@ -158,7 +176,7 @@ def main():
         triplets = world * (args.batch // 2) * args.steps / dt
         images = 2 * triplets
         out = {
-            "metric": "triplets/sec (whole node) EFM 112x112 bs256/GPU", "value": round(triplets, 2), "unit": "triplets/s",
+            "metric": baseline_metric(), "value": round(triplets, 2), "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: EFM-29 128-d embedding, %d images/GPU of %dx%dx3, fp32, "
@@ -172,7 +190,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.image, torch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

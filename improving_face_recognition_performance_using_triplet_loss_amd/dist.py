@@ -8,6 +8,8 @@ moment its last slice arrives, so the exchange of the deep layers hides under th
 ones.  xGMI is point-to-point: few large messages beat many small ones, hence 4-8 buckets, not per-layer.
 Sum, not mean: the 1/global_batch scale is the optimiser's `rescale` (ref: mutli_gpu_v3.py:159).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,6 +22,8 @@ class BucketReducer:
         assert self.bounds[0] == 0 and self.bounds[-1] == grad_flat.numel()
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # rehearsal knob: issue the collectives even with a single rank (exercises the RCCL stream semantics on a 1-GPU box)
+        self.force = bool(os.environ.get("EFM_FORCE_ALLREDUCE")) and dist.is_initialized()
         self._pending = None
         self._handles = []
         self.launch_order = []
@@ -60,7 +64,7 @@ class BucketReducer:
 
     def _launch(self, k):
         self.launch_order.append(k)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         view = self.grad.narrow(0, self.bounds[k], self.bounds[k + 1] - self.bounds[k])
         self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))

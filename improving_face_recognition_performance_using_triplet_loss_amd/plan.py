@@ -401,7 +401,9 @@ class Plan:
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # a high-priority stream gets a hardware queue of its own even after RCCL has created its streams
+            # (with a default-priority stream the overlap disappeared once a process group existed: measured)
+            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
         return self._side
 
     def routing_inputs(self):
