@@ -58,6 +58,8 @@ SIGNATURES = {
     "efm_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_triplet_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "efm_triplet_bwd": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "efm_triplet_indexed_fwd": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_float, c_void_p]),
+    "efm_triplet_indexed_bwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     "efm_cosine_pairs": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "efm_pair_distance": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "efm_gram_cosine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -145,6 +145,49 @@ __global__ void __launch_bounds__(256) triplet_bwd_k(const float* __restrict__ a
   }
 }
 
+// ---- triplet loss over index vectors (in-batch mining): anchor i = row anchor[i]... here every row is an anchor ----------
+// loss[i] = relu(|e_i - e_pos[i]|^2 - |e_i - e_neg[i]|^2 + margin); rows with neg[i] < 0 (no other identity) give 0.
+__global__ void __launch_bounds__(256) triplet_indexed_fwd_k(const float* __restrict__ e, const int32_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ neg, float* __restrict__ loss,
+                                                             int rows, int d, int lde, float margin) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int ni = neg[row];
+  if (ni < 0) {
+    if (lane == 0) loss[row] = 0.f;
+    return;
+  }
+  const float* ar = e + (long)row * lde;
+  const float* pr = e + (long)pos[row] * lde;
+  const float* nr = e + (long)ni * lde;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float dp = pr[k] - ar[k], dn = nr[k] - ar[k];
+    s += dp * dp - dn * dn;
+  }
+  s = wave_sum(s);
+  if (lane == 0) loss[row] = fmaxf(s + margin, 0.f);
+}
+
+// de[i] = 2 g_i (e_neg[i] - e_pos[i])            (row i as anchor)
+//       + 2 g_j (e_i - e_j),  j = inv_pos[i]      (row i as the positive of anchor j; pos is a permutation)
+// negatives are detached (ref: train_efm.py:238-239).  No atomics: every output row is written by one wave.
+__global__ void __launch_bounds__(256) triplet_indexed_bwd_k(const float* __restrict__ e, const int32_t* __restrict__ pos,
+                                                             const int32_t* __restrict__ neg, const int32_t* __restrict__ inv_pos,
+                                                             const float* __restrict__ loss, const float* __restrict__ gloss,
+                                                             float* __restrict__ de, int rows, int d, int lde, int ldg) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int j = inv_pos[row];
+  const float gi = (loss[row] > 0.f) ? 2.f * gloss[row] : 0.f;
+  const float gj = (j >= 0 && loss[j] > 0.f) ? 2.f * gloss[j] : 0.f;
+  const float* er = e + (long)row * lde;
+  const float* pr = e + (long)pos[row] * lde;
+  const float* nr = e + (long)(neg[row] < 0 ? row : neg[row]) * lde;
+  const float* jr = e + (long)(j < 0 ? row : j) * lde;
+  for (int k = lane; k < d; k += 64) de[(long)row * ldg + k] = gi * (nr[k] - pr[k]) + gj * (er[k] - jr[k]);
+}
+
 // ---- cosine similarities -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cosine_pairs_k(const float* __restrict__ a, const float* __restrict__ p,
                                                       const float* __restrict__ n, float* __restrict__ s_ap,
@@ -322,6 +365,21 @@ int efm_triplet_bwd(const float* a, const float* p, const float* n, const float*
   EFM_REQUIRE(a && p && n && loss && gloss && rows > 0 && d > 0, "triplet_bwd: bad argument");
   hipLaunchKernelGGL(triplet_bwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, p, n, loss, gloss, da, dp, dn, rows, d, lda, ldp, ldn, ldg);
   return efm::check_launch("triplet_bwd");
+}
+
+int efm_triplet_indexed_fwd(const float* e, const int32_t* pos, const int32_t* neg, float* loss, int rows, int d, int lde,
+                            float margin, void* stream) {
+  EFM_REQUIRE(e && pos && neg && loss && rows > 0 && d > 0, "triplet_indexed_fwd: bad argument");
+  hipLaunchKernelGGL(triplet_indexed_fwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, e, pos, neg, loss, rows, d, lde, margin);
+  return efm::check_launch("triplet_indexed_fwd");
+}
+
+int efm_triplet_indexed_bwd(const float* e, const int32_t* pos, const int32_t* neg, const int32_t* inv_pos, const float* loss,
+                            const float* gloss, float* de, int rows, int d, int lde, int ldg, void* stream) {
+  EFM_REQUIRE(e && pos && neg && inv_pos && loss && gloss && de && rows > 0 && d > 0, "triplet_indexed_bwd: bad argument");
+  hipLaunchKernelGGL(triplet_indexed_bwd_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, e, pos, neg, inv_pos, loss, gloss, de,
+                     rows, d, lde, ldg);
+  return efm::check_launch("triplet_indexed_bwd");
 }
 
 int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap, float* s_an, int rows, int d,

@@ -74,3 +74,30 @@ def embedding_net(embed_dim=128, normalize=True, fc_hidden=513):
     x = G.L2Normalization(feat, name="l2norm") if normalize else feat
     emb = G.FullyConnected(x, embed_dim, name="head", no_bias=True)
     return [emb, feat]
+
+
+LIGHTCNN9_PLAN = [  # (name, 1x1 channels or 0, kxk channels, kernel, pad, pool) — BASELINE configs[2], SURVEY.md §8d
+    ("1", 0, 96, 5, 2, True), ("2", 96, 192, 3, 1, True), ("3", 192, 384, 3, 1, True), ("4", 384, 256, 3, 1, False),
+    ("5", 256, 256, 3, 1, True)]
+
+
+def lightcnn9_feature(data, fc_hidden=512):
+    """LightCNN-9 (build-defined: the reference only carries its 2-way MFM branch, efm_symbol.py:62-64,76-77):
+    conv5x5(96) MFM2 pool, then [conv1x1 -> MFM2 -> conv3x3 -> MFM2 (-> pool)] x 4, fc -> MFM2 -> 256-d."""
+    x = data
+    for layer, num_r, num, k, pad, pool in LIGHTCNN9_PLAN:
+        if num_r:
+            x = G.MFM(G.Convolution(x, num_r, (1, 1), name="conv%s_r" % layer), 2, G.ORDER_GROUP, name="mfm%s_r" % layer)
+        x = G.MFM(G.Convolution(x, num, (k, k), name="conv%s" % layer, pad=(pad, pad)), 2, G.ORDER_GROUP, name="mfm%s" % layer)
+        if pool:
+            x = G.Pooling(x, name="pool%s" % layer)
+    fc1 = G.FullyConnected(x, fc_hidden, name="fc1")
+    return G.MFM(fc1, 2, G.ORDER_GROUP, name="mfm_fc1")
+
+
+def lightcnn9_embedding_net(normalize=True):
+    """[256-d embedding (per-row L2 normalised), raw 256-d feature]."""
+    data = G.Variable("data")
+    feat = lightcnn9_feature(data)
+    emb = G.L2Normalization(feat, name="l2norm") if normalize else feat
+    return [emb, feat]

@@ -276,6 +276,24 @@ def triplet_bwd(a, p, n, loss, gloss, need_dn=False, da=None, dp=None, dn=None):
     return da, dp, dn
 
 
+def triplet_indexed_fwd(e, pos, neg, margin):
+    _need_rows(e)
+    rows, d = e.shape
+    loss = torch.empty((rows,), dtype=torch.float32, device=e.device)
+    check(_lib.load().efm_triplet_indexed_fwd(_p(e), _p(pos), _p(neg), _p(loss), rows, d, _ld(e), float(margin), _stream()), "efm_triplet_indexed_fwd")
+    return loss
+
+
+def triplet_indexed_bwd(e, pos, neg, inv_pos, loss, gloss, out=None):
+    _need_rows(e, out)
+    rows, d = e.shape
+    if out is None:
+        out = torch.empty((rows, d), dtype=torch.float32, device=e.device)
+    check(_lib.load().efm_triplet_indexed_bwd(_p(e), _p(pos), _p(neg), _p(inv_pos), _p(loss), _p(gloss), _p(out), rows, d, _ld(e), _ld(out),
+                                              _stream()), "efm_triplet_indexed_bwd")
+    return out
+
+
 def cosine_pairs(a, p, n):
     _need_rows(a, p, n)
     rows, d = a.shape

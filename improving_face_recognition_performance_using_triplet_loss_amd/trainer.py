@@ -78,3 +78,48 @@ class TripletTrainer:
         """(s_ap, s_an) of the last step — the rows the reference appends to cosine_similarity.csv (train_efm.py:251-255)."""
         L = self.last
         return ops.cosine_pairs(L["a"], L["p"], L["n"])
+
+
+class MiningTripletTrainer(TripletTrainer):
+    """Batch-all anchors with in-batch semi-hard negatives (north star; BASELINE configs[2]): every image is an anchor,
+    its positive is the next image of the same identity, its negative comes from the batch cosine matrix
+    (`efm_gram_cosine` + `efm_mine_semihard`), detached like the reference's negatives.  All on device, no host sync."""
+
+    def set_labels(self, labels):
+        import numpy as np
+        lab = np.asarray(labels.cpu() if torch.is_tensor(labels) else labels)
+        pos = np.arange(len(lab), dtype=np.int32)
+        for v in np.unique(lab):
+            idx = np.nonzero(lab == v)[0]
+            pos[idx] = np.roll(idx, -1)
+        inv = np.empty_like(pos)
+        inv[pos] = np.arange(len(lab), dtype=np.int32)
+        self.labels = torch.as_tensor(lab.astype(np.int32)).to(self.device)
+        self.pos = torch.as_tensor(pos).to(self.device)
+        self.inv_pos = torch.as_tensor(inv).to(self.device)
+        self.anchor = torch.arange(len(lab), dtype=torch.int32, device=self.device)
+        self._ones = torch.ones(len(lab), dtype=torch.float32, device=self.device)
+        self.n_anchor = len(lab)
+
+    def forward_loss(self, x, neg_idx=None):
+        emb, feat = self.plan.forward(x, self.flat, train=True)
+        g = ops.gram_cosine(emb)
+        neg = ops.mine_semihard(g, self.labels, self.anchor, self.pos) if neg_idx is None else neg_idx
+        loss = ops.triplet_indexed_fwd(emb, self.pos, neg, self.margin)
+        self.last = {"emb": emb, "feat": feat, "neg": neg, "loss": loss, "gram": g}
+        return loss
+
+    def backward(self, demb=None):
+        L = self.last
+        if demb is None:
+            demb = ops.triplet_indexed_bwd(L["emb"], self.pos, L["neg"], self.inv_pos, L["loss"], self._ones)
+        self.plan.backward([demb, None], self.flat, self.grad, ready_cb=self.reducer.ready)
+        self.reducer.finish()
+
+    def update(self):
+        self.t += 1
+        rescale = 1.0 / (self.n_anchor * self.world)
+        if self.optimizer == "sgd":
+            ops.sgd_update(self.flat, self.grad, self.lr, self.wd, rescale)
+        else:
+            ops.adam_update(self.flat, self.grad, self.m, self.v, self.lr, self.t, wd=self.wd, rescale=rescale)

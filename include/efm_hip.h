@@ -157,6 +157,14 @@ int efm_triplet_fwd(const float* a, const float* p, const float* n, float* loss,
 int efm_triplet_bwd(const float* a, const float* p, const float* n, const float* loss, const float* gloss,
                     float* da, float* dp, float* dn, int rows, int d, int lda, int ldp, int ldn, int ldg,
                     void* stream);
+/* The same loss with every row of e an anchor and positives / negatives given as row indices (in-batch mining, north star):
+ * loss[i] = relu(|e_i - e_pos[i]|^2 - |e_i - e_neg[i]|^2 + margin), 0 where neg[i] < 0.  pos must be a permutation of the rows
+ * (inv_pos its inverse, -1 where a row is nobody's positive); negatives are detached as in the reference, so
+ * de[i] = 2 g_i (e_neg[i] - e_pos[i]) + 2 g_j (e_i - e_j), j = inv_pos[i] — one writer per row, no atomics. */
+int efm_triplet_indexed_fwd(const float* e, const int32_t* pos, const int32_t* neg, float* loss, int rows, int d, int lde,
+                            float margin, void* stream);
+int efm_triplet_indexed_bwd(const float* e, const int32_t* pos, const int32_t* neg, const int32_t* inv_pos, const float* loss,
+                            const float* gloss, float* de, int rows, int d, int lde, int ldg, void* stream);
 /* s_ap[i] = cos(a_i,p_i), s_an[i] = cos(a_i,n_i) — cosine_dist (ref: train_efm.py:26-34). */
 int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap, float* s_an, int rows,
                      int d, int lda, int ldp, int ldn, void* stream);

@@ -226,6 +226,33 @@ def mine_semihard(g, labels, anchor_idx, pos_idx):
     return out
 
 
+def mining_indices(labels):
+    """Batch-all layout helper: positive of row i = the next row of the same identity (cyclic) -> a permutation;
+    rows whose identity appears once are their own positive (d_ap = 0, as define_pos allows, train_efm.py:42-43)."""
+    labels = np.asarray(labels)
+    pos = np.arange(len(labels), dtype=np.int32)
+    for lab in np.unique(labels):
+        idx = np.nonzero(labels == lab)[0]
+        pos[idx] = np.roll(idx, -1)
+    inv = np.empty_like(pos)
+    inv[pos] = np.arange(len(labels), dtype=np.int32)
+    return pos, inv
+
+
+def triplet_indexed(e, pos, neg, margin):
+    ok = neg >= 0
+    n = e[np.where(ok, neg, 0)]
+    return np.where(ok, triplet_loss(e, e[pos], n, margin), 0.0)
+
+
+def triplet_indexed_bwd(e, pos, neg, loss, gloss):
+    """d(sum_i gloss_i loss_i)/de with the negatives detached."""
+    g = np.where(loss > 0, 2.0 * gloss, 0.0)[:, None]
+    de = g * (e[np.where(neg >= 0, neg, 0)] - e[pos])     # as anchor
+    np.add.at(de, pos, g * (e[pos] - e))                  # as positive of anchor i
+    return de
+
+
 def softmax_cross_entropy(logits, labels):
     """SoftmaxCrossEntropyLoss, sparse labels, per-sample.  [MX-assumed (8)]  ref: train_efm.py:211,242."""
     z = logits - logits.max(axis=1, keepdims=True)

@@ -68,3 +68,36 @@ def train_step(p, w_head, x, neg_idx, margin, demb=None):
     else:
         emb.backward(demb)
     return loss.detach(), emb.detach(), feat.detach()
+
+
+LIGHTCNN9_PLAN = [("1", 0, 96, 5, 2, True), ("2", 96, 192, 3, 1, True), ("3", 192, 384, 3, 1, True), ("4", 384, 256, 3, 1, False),
+                  ("5", 256, 256, 3, 1, True)]
+
+
+def lightcnn9_forward(p, x):
+    """Build-defined LightCNN-9 (BASELINE configs[2]): 2-way MFM everywhere (ref branch: efm_symbol.py:62-64,76-77)."""
+    cur = x
+    for layer, num_r, num, k, pad, pool in LIGHTCNN9_PLAN:
+        if num_r:
+            cur = mfm2(F.conv2d(cur, p["conv%s_r_weight" % layer], p["conv%s_r_bias" % layer]))
+        cur = mfm2(F.conv2d(cur, p["conv%s_weight" % layer], p["conv%s_bias" % layer], padding=pad))
+        if pool:
+            cur = F.max_pool2d(cur, 2, 2)
+    return mfm2(F.linear(cur.flatten(1), p["fc1_weight"], p["fc1_bias"]))
+
+
+def mining_step(forward, p, x, labels, pos, margin):
+    """Semi-hard step on any feature network: emb = rownorm(forward), cosine matrix, TF-addons semi-hard rule, indexed
+    triplet loss with detached negatives; returns (loss, emb, neg); gradients land in .grad of `p`."""
+    from oracle import efm_oracle as O
+    feat = forward(p, x)
+    emb = feat / feat.norm(dim=1, keepdim=True)
+    e = emb.detach().numpy()
+    g = O.gram_cosine(e)
+    import numpy as np
+    neg = O.mine_semihard(g, labels, np.arange(len(labels)), pos)
+    ok = torch.as_tensor(neg >= 0)
+    n = emb[torch.as_tensor(np.where(neg >= 0, neg, 0))].detach()
+    loss = torch.where(ok, triplet_loss(emb, emb[torch.as_tensor(pos.astype(np.int64))], n, margin), torch.zeros((), dtype=emb.dtype))
+    loss.sum().backward()
+    return loss.detach(), emb.detach(), neg
