@@ -245,11 +245,12 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
     vmax = fmaxf(m1, x2);
     vmin = fminf(n1, x2);
   };
+  // The K loop ended with a block barrier, so the staging buffers are dead.  From here on a wave only touches its own
+  // region, and the DS operations of one wave execute in program order: no further barrier is needed.
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int h = 0; h < 16 / R; ++h) {
-      __syncthreads();  // LDS free: K-loop reads / previous pass reads are done
       if (R == 16 || (fq >> 1) == h) {
         const int rr = (R == 16) ? 4 * fq : 4 * (fq & 1);
 #pragma unroll
@@ -260,7 +261,8 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
           for (int r = 0; r < 4; ++r) Es[(rr + r) * ES + n] = acc[mt][nt][r] + bv;
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const int row0 = m0 + wave * (MT * 16) + mt * 16 + h * R;  // first result row of this pass
       if (p.pool) {
 #pragma unroll
@@ -777,16 +779,19 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   WgradPlan pl;
   const int M = d->batch * d->hout * d->wout;
   const int ktiles = d->k_pad / 16, ntiles = d->n_pad16 / 16;
-  pl.KPW = env_int("EFM_WGRAD_KPW", (ktiles >= 32) ? 2 : 1);
+  // 8 k-tiles per block whenever that saves a k-block: dy is re-read once per k-block, and the narrow-K layers
+  // (conv1: K = 100, the 1x1 convolutions) are bound by exactly that traffic.
+  pl.KPW = env_int("EFM_WGRAD_KPW", (ktiles >= 5) ? 2 : 1);
   if (pl.KPW != 2) pl.KPW = 1;
   pl.kblocks = (ktiles + 4 * pl.KPW - 1) / (4 * pl.KPW);
   const int nb = (ntiles + 12) / 13;
   pl.NTW = round_nt((ntiles + nb - 1) / nb);
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
-  const int target = env_int("EFM_WGRAD_BLOCKS", 1536);
+  // measured on EFM-29 @ B=256: ~10 blocks per CU, but never fewer than 768 pixels (48 K steps) per block
+  const int target = env_int("EFM_WGRAD_BLOCKS", 2560);
   int splits = (target + base - 1) / base;
-  const int max_splits = (M + 255) / 256;  // at least 256 pixels (16 steps) per split
+  const int max_splits = (M + 767) / 768;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = (M + splits - 1) / splits;
