@@ -80,6 +80,9 @@ def load():
         raise EfmError(
             "HIP extension %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64; loading ours before it would bind this library to a second HIP runtime
+    # in the same process (seen as "no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch
