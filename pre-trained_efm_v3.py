@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from improving_face_recognition_performance_using_triplet_loss_amd import functional as F_
+from improving_face_recognition_performance_using_triplet_loss_amd import mxio
 from improving_face_recognition_performance_using_triplet_loss_amd.data import CSVIter, DataIter, define_pos, pick_negatives, synthetic_source
 from improving_face_recognition_performance_using_triplet_loss_amd.nn import Dense, Trainer, TripletLoss
 
@@ -111,7 +112,7 @@ def main(argv=None):
                 loss, _ = run(batch, False)
                 valid_loss += loss.mean().item()
         paramfile = "fc_efm_res-%04d.params" % (epoch)
-        torch.save({"dense0_weight": net.weight_mx().cpu()}, paramfile)
+        mxio.save_params(paramfile, {"dense0_weight": net.weight_mx().cpu().numpy()})  # MXNet NDArray-list format
         print("Epoch {}: train loss {:g}, valid loss {:g}, in {:.1f} sec".format(
             epoch, train_loss / epoch_size, valid_loss / (Testing_IMG_number / batch_size), time.time() - tic), flush=True)
 

@@ -29,6 +29,10 @@ def test_train_efm_entry_point(tmp_path):
     assert len(rows) == 2 * 4 * 8  # epochs x steps x batch rows, "s_ap s_an"
     assert all(len(r.split(" ")) == 2 and -1.0001 <= float(r.split(" ")[0]) <= 1.0001 for r in rows)
     assert (tmp_path / "efm_res-0000.params").exists() and (tmp_path / "efm_res-0001.params").exists()
+    from improving_face_recognition_performance_using_triplet_loss_amd import mxio
+    saved = mxio.load_params(str(tmp_path / "efm_res-0001.params"))
+    assert saved["g1_conv1_weight"].shape == (99, 1, 5, 5) and saved["fc1_weight"].shape == (1026, 174)  # 32x32 input -> 1x1 map
+    assert saved["dense1_weight"].shape == (16, 684)
     assert os.listdir(tmp_path / "try2_efm_light_29_134" / "log")
 
 
@@ -36,7 +40,8 @@ def test_pretrained_head_entry_point(tmp_path):
     out = _run("pre-trained_efm_v3.py", ["--synthetic", "512", "--epochs", "3", "--batch-size", "64"], str(tmp_path))
     losses = [float(v) for v in re.findall(r"Epoch \d+: train loss ([\d.eE+-]+), valid loss", out)]
     assert len(losses) == 3 and all(np.isfinite(losses))
-    w = torch.load(tmp_path / "fc_efm_res-0002.params", weights_only=True)["dense0_weight"]
+    from improving_face_recognition_performance_using_triplet_loss_amd import mxio
+    w = mxio.load_params(str(tmp_path / "fc_efm_res-0002.params"))["dense0_weight"]
     assert tuple(w.shape) == (128, 342)
     assert len(open(tmp_path / "cosine_similarity.csv").read().strip().splitlines()) == 3 * 8 * 64
 
@@ -80,3 +85,15 @@ def test_lightcnn29_forward_shapes_and_shared_weight_gradients():
         want = gb[k.replace("rb_", "rb_a_")] + gb[k.replace("rb_", "rb_b_")]
         assert torch.allclose(ga[k], want, rtol=1e-4, atol=1e-6), k
     assert torch.allclose(ga["stem_weight"], gb["stem_weight"], rtol=1e-4, atol=1e-6)
+
+
+def test_train_efm_reads_recordio(tmp_path):
+    """The reference's input format: <root>/{train,test}.rec + .lst (ref: train_efm.py:135-148,179-181)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import mxio
+    rng = np.random.default_rng(0)
+    for split, n in (("train", 16), ("test", 8)):
+        recs = [mxio.pack_img(float(i % 4), i, rng.integers(0, 256, size=(36, 36), dtype=np.uint8)) for i in range(n)]
+        mxio.write_records(str(tmp_path / (split + ".rec")), recs)
+        (tmp_path / (split + ".lst")).write_text("".join("%d\t%f\timg%d.png\n" % (i, i % 4, i) for i in range(n)))
+    out = _run("train_efm.py", [str(tmp_path), "--epochs", "1", "--batch-size", "8", "--image-size", "32", "--classes", "4"], str(tmp_path))
+    assert "Totoal number of training samples =  16" in out and re.search(r"Epoch 0: train loss", out)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Drop-in for the reference's train_efm.py: end-to-end training of LightCNN_29 with softmax-ID loss + alpha * triplet loss.
 
-    python train_efm.py <root>                       # <root>/{train,test}.npz  (data (N,C,H,W) in [0,1], label (N,))
+    python train_efm.py <root>                       # <root>/{train,test}.rec (+ .lst), as the reference; or {train,test}.npz
     python train_efm.py <root> --synthetic 512       # no dataset on disk: splitmix64 faces, on-device training
 
 Same hyper-parameters, loop structure and observable outputs as the reference (ref: train_efm.py:154-167 constants,
@@ -9,8 +9,8 @@ Same hyper-parameters, loop structure and observable outputs as the reference (r
 "Epoch N: train loss ..., in T sec" line per epoch (:292-294), efm_res-%04d.params per epoch (:289-290), log file under
 try2_efm_light_29_134/log/ (:163-171).  Deliberate deviations from the reference as committed:
 `mx.nd.nrom` is read as `norm` (whole-matrix normalisation, kept; --row-norm gives the per-row north-star variant);
-a batch holding one identity raises instead of looping forever; the RecordIO reader is not part of this round
-(.npz or --synthetic instead of train.rec/test.rec).
+a batch holding one identity raises instead of looping forever; RecordIO images are decoded on the host by `mxio.ImageRecordIter`
+(same options: scale 1/255, rand_crop, rand_mirror, shuffle).
 """
 import argparse
 import csv
@@ -49,13 +49,21 @@ def acc(output, label):
 
 def load_split(root, name, args, seed):
     path = os.path.join(root, name + ".npz")
+    rec = os.path.join(root, name + ".rec")
+    if not args.synthetic and os.path.exists(rec):
+        from improving_face_recognition_performance_using_triplet_loss_amd.mxio import ImageRecordIter
+        it = ImageRecordIter(path_imgrec=rec, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True,
+                             data_shape=(args.channels, args.image_size, args.image_size), batch_size=args.batch_size, seed=seed)
+        lst = os.path.join(root, name + ".lst")
+        n = len(open(lst).readlines()) if os.path.exists(lst) else len(it.data_arr)
+        return it, n
     if args.synthetic:
         ids = max(args.synthetic // 4, 2)
         return synthetic_source(args.synthetic, (args.channels, args.image_size, args.image_size), min(ids, args.classes), seed, args.batch_size), args.synthetic
     if os.path.exists(path):
         z = np.load(path)
         return ArrayIter(torch.from_numpy(z["data"].astype(np.float32)), torch.from_numpy(z["label"].astype(np.float32)), args.batch_size), len(z["label"])
-    raise SystemExit("no %s found; RecordIO (.rec) input is not supported in this round — pass --synthetic N or provide %s.npz" % (path, name))
+    raise SystemExit("no %s or %s found — pass --synthetic N" % (rec, path))
 
 
 def main(argv=None):
