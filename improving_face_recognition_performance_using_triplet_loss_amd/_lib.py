@@ -64,6 +64,13 @@ SIGNATURES = {
     "efm_pair_distance": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "efm_gram_cosine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "efm_mine_semihard": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "efm_pred_create": (c_int, [c_char_p, c_void_p, c_int, c_int, ctypes.c_uint32, POINTER(c_char_p), POINTER(ctypes.c_uint32),
+                               POINTER(ctypes.c_uint32), POINTER(c_void_p)]),
+    "efm_pred_set_input": (c_int, [c_void_p, c_char_p, c_void_p, ctypes.c_uint32]),
+    "efm_pred_forward": (c_int, [c_void_p]),
+    "efm_pred_get_output_shape": (c_int, [c_void_p, ctypes.c_uint32, POINTER(POINTER(ctypes.c_uint32)), POINTER(ctypes.c_uint32)]),
+    "efm_pred_get_output": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32]),
+    "efm_pred_free": (c_int, [c_void_p]),
     "efm_sgd_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),
     "efm_adam_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_int, c_void_p]),
 }

@@ -1,0 +1,282 @@
+// Native EFM-29 feature predictor with the call shape of MXNet's C predict API.
+//
+// The reference's deployment code drives the trained network through MXPredCreatePartialOut / MXPredSetInput /
+// MXPredForward / MXPredGetOutputShape / MXPredGetOutput / MXPredFree (ref: feature_extraction/c_version/Feature.hpp:163-205)
+// and reads the 342-d 'concat29_output' feature (Feature.hpp:24 fvSize = 342).  This file is the drop-in for that consumer
+// side on an MI355X: the network structure is the Symbol EFM-29 (ref: efm_symbol.py:22-101), parameters come from an MXNet
+// NDArray-list blob (the bytes of an `.params` file), the forward pass is the same fused HIP kernels the trainer uses.
+// Unlike the operator entry points, a predictor OWNS its device buffers (as an MXNet predictor does).
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "efm_common.h"
+
+namespace {
+
+struct Blob {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+bool parse_params(const unsigned char* buf, size_t size, std::map<std::string, Blob>& out) {
+  size_t off = 0;
+  auto need = [&](size_t n) { return off + n <= size; };
+  auto rd64 = [&](uint64_t& v) { if (!need(8)) return false; memcpy(&v, buf + off, 8); off += 8; return true; };
+  auto rd32 = [&](uint32_t& v) { if (!need(4)) return false; memcpy(&v, buf + off, 4); off += 4; return true; };
+  uint64_t magic, reserved, count;
+  if (!rd64(magic) || !rd64(reserved) || !rd64(count) || magic != 0x112) return false;
+  std::vector<Blob> arrays(count);
+  for (uint64_t i = 0; i < count; ++i) {
+    uint32_t m, ndim;
+    if (!rd32(m)) return false;
+    if (m == 0xF993FAC9u || m == 0xF993FACAu) {
+      uint32_t stype;
+      if (!rd32(stype) || stype != 0 || !rd32(ndim)) return false;
+    } else if (m == 0xF993FAC8u) {
+      if (!rd32(ndim)) return false;
+    } else {
+      return false;  // legacy (pre-1.0) records are not accepted here
+    }
+    Blob& b = arrays[i];
+    size_t n = 1;
+    for (uint32_t d = 0; d < ndim; ++d) {
+      uint64_t v;
+      if (!rd64(v)) return false;
+      b.shape.push_back((int64_t)v);
+      n *= (size_t)v;
+    }
+    if (ndim == 0) continue;
+    uint32_t dev_type, dev_id, flag;
+    if (!rd32(dev_type) || !rd32(dev_id) || !rd32(flag) || flag != 0) return false;  // float32 only
+    if (!need(n * 4)) return false;
+    b.data.resize(n);
+    memcpy(b.data.data(), buf + off, n * 4);
+    off += n * 4;
+  }
+  uint64_t ncount;
+  if (!rd64(ncount) || ncount != count) return false;
+  for (uint64_t i = 0; i < count; ++i) {
+    uint64_t len;
+    if (!rd64(len) || !need(len)) return false;
+    std::string name((const char*)buf + off, (size_t)len);
+    off += len;
+    if (name.rfind("arg:", 0) == 0 || name.rfind("aux:", 0) == 0) name = name.substr(4);
+    out[name] = std::move(arrays[i]);
+  }
+  return true;
+}
+
+struct Op {
+  int kind;  // 0 conv plain (+residual), 1 conv fused mfm (pool flag), 2 standalone mfm
+  efm_conv_desc d;
+  float *w = nullptr, *bias = nullptr, *out = nullptr;
+  unsigned char* route = nullptr;
+  const float *in = nullptr, *res = nullptr;
+  int ways = 3, order = 0, pool = 0, c = 0;
+  int64_t rows = 0;
+};
+
+struct Predictor {
+  int batch = 0, c = 0, h = 0, w = 0, feat = 342;
+  float *x_nchw = nullptr, *x_nhwc = nullptr, *feat_dev = nullptr;
+  std::vector<Op> ops;
+  std::vector<void*> owned;
+  uint32_t out_shape[2] = {0, 0};
+  hipStream_t stream = nullptr;
+  ~Predictor() {
+    for (void* p : owned) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  template <class T>
+  T* alloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+    owned.push_back(p);
+    return (T*)p;
+  }
+};
+
+struct Cur {
+  const float* p;
+  int c, h, w;
+};
+
+// conv (+ bias) with epilogue mode; returns false on a missing parameter / allocation failure
+bool add_conv(Predictor& P, const std::map<std::string, Blob>& params, const std::string& name, Cur& cur, int cout, int k, int pad,
+              int mode, int order, const float* residual) {
+  auto wi = params.find(name + "_weight"), bi = params.find(name + "_bias");
+  if (wi == params.end() || bi == params.end()) {
+    efm::set_error("pred_create: parameter %s_weight / _bias missing", name.c_str());
+    return false;
+  }
+  Op op;
+  op.kind = mode ? 1 : 0;
+  int kh = k, kw = k;
+  if (k == 0) { kh = cur.h; kw = cur.w; }  // fully connected = 'valid' conv over the whole map
+  if (efm_conv_desc_init(&op.d, P.batch, cur.h, cur.w, cur.c, cout, kh, kw, pad, pad) != EFM_OK) return false;
+  const size_t expect = (size_t)cout * cur.c * kh * kw;
+  if (wi->second.data.size() != expect || (int)bi->second.data.size() != cout) {
+    efm::set_error("pred_create: %s has %zu weights, expected %zu", name.c_str(), wi->second.data.size(), expect);
+    return false;
+  }
+  float* w_oihw = P.alloc<float>(expect);
+  op.w = P.alloc<float>(efm_conv_weight_elems(&op.d));
+  op.bias = P.alloc<float>(op.d.n_pad16);
+  if (!w_oihw || !op.w || !op.bias) return false;
+  if (hipMemcpy(w_oihw, wi->second.data.data(), expect * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(op.bias, 0, op.d.n_pad16 * 4) != hipSuccess ||
+      hipMemcpy(op.bias, bi->second.data.data(), cout * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    efm::set_error("pred_create: uploading %s failed", name.c_str());
+    return false;
+  }
+  if (efm_conv_pack_weights(&op.d, w_oihw, op.w, P.stream) != EFM_OK) return false;
+  op.in = cur.p;
+  op.res = residual;
+  op.order = order;
+  int oc = cout, oh = op.d.hout, ow = op.d.wout;
+  if (mode) {
+    op.pool = (mode == 2);
+    oc = 2 * cout / 3;
+    if (op.pool) { oh /= 2; ow /= 2; }
+    op.route = P.alloc<unsigned char>((size_t)P.batch * oh * ow * efm_pad4(oc));
+    if (!op.route) return false;
+  }
+  op.out = P.alloc<float>((size_t)P.batch * oh * ow * efm_pad4(oc));
+  if (!op.out) return false;
+  P.ops.push_back(op);
+  cur = Cur{op.out, oc, oh, ow};
+  return true;
+}
+
+bool add_mfm(Predictor& P, Cur& cur, int order) {
+  Op op;
+  op.kind = 2;
+  op.in = cur.p;
+  op.c = cur.c;
+  op.order = order;
+  op.rows = (int64_t)P.batch * cur.h * cur.w;
+  const int oc = 2 * cur.c / 3;
+  op.out = P.alloc<float>((size_t)op.rows * efm_pad4(oc));
+  if (!op.out) return false;
+  P.ops.push_back(op);
+  cur = Cur{op.out, oc, cur.h, cur.w};
+  return true;
+}
+
+bool build_efm29(Predictor& P, const std::map<std::string, Blob>& params) {
+  // the five group() calls of efm_symbol.py:84-92: (num_r, num, kernel, pad, layer, res blocks)
+  static const int G[5][5] = {{0, 99, 5, 2, 0}, {99, 198, 3, 1, 1}, {198, 387, 3, 1, 2}, {387, 261, 3, 1, 3}, {261, 261, 3, 1, 4}};
+  Cur cur{P.x_nhwc, P.c, P.h, P.w};
+  for (int g = 0; g < 5; ++g) {
+    const std::string layer = std::to_string(g + 1);
+    const int num_r = G[g][0], num = G[g][1], k = G[g][2], pad = G[g][3], tar = G[g][4];
+    if (num_r > 0) {
+      for (int x = 0; x < tar; ++x) {  // res_block (efm_symbol.py:22-44)
+        const std::string ln = x == 0 ? layer : layer + std::to_string(x);
+        const Cur data = cur;
+        if (!add_mfm(P, cur, EFM_MFM_ORDER_RES)) return false;
+        if (!add_conv(P, params, "conv" + ln + "_res", cur, num_r, 3, 1, 1, EFM_MFM_ORDER_RES, nullptr)) return false;
+        if (!add_conv(P, params, "conv" + ln + "_res_r", cur, num_r * 2 / 3, 3, 1, 0, 0, data.p)) return false;
+      }
+      if (!add_conv(P, params, "conv" + layer + "_r", cur, num_r, 1, 0, 1, EFM_MFM_ORDER_RES, nullptr)) return false;
+    }
+    if (!add_conv(P, params, "conv" + layer, cur, num, k, pad, 2, EFM_MFM_ORDER_GROUP, nullptr)) return false;
+  }
+  if (!add_conv(P, params, "fc1", cur, 513, 0, 0, 0, 0, nullptr)) return false;
+  if (!add_mfm(P, cur, EFM_MFM_ORDER_RES)) return false;  // 'concat29_output': the 342-d feature
+  P.feat = cur.c;
+  P.feat_dev = const_cast<float*>(cur.p);
+  P.out_shape[0] = (uint32_t)P.batch;
+  P.out_shape[1] = (uint32_t)P.feat;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int efm_pred_create(const char* symbol_json, const void* param_bytes, int param_size, int dev_id, uint32_t num_input_nodes,
+                    const char** input_keys, const uint32_t* input_shape_indptr, const uint32_t* input_shape_data,
+                    void** out) {
+  (void)symbol_json;
+  EFM_REQUIRE(param_bytes && param_size > 0 && out, "pred_create: null argument");
+  EFM_REQUIRE(num_input_nodes == 1 && input_keys && std::string(input_keys[0]) == "data", "pred_create: the one input is 'data'");
+  EFM_REQUIRE(input_shape_indptr && input_shape_data && input_shape_indptr[1] - input_shape_indptr[0] == 4,
+              "pred_create: input shape must be (N, C, H, W)");
+  if (hipSetDevice(dev_id) != hipSuccess) {
+    efm::set_error("pred_create: hipSetDevice(%d) failed", dev_id);
+    return EFM_E_LAUNCH;
+  }
+  std::map<std::string, Blob> params;
+  if (!parse_params((const unsigned char*)param_bytes, (size_t)param_size, params)) {
+    efm::set_error("pred_create: not a float32 MXNet NDArray-list blob");
+    return EFM_E_INVALID;
+  }
+  Predictor* P = new Predictor();
+  const uint32_t* s = input_shape_data + input_shape_indptr[0];
+  P->batch = (int)s[0]; P->c = (int)s[1]; P->h = (int)s[2]; P->w = (int)s[3];
+  if (hipStreamCreate(&P->stream) != hipSuccess) {
+    delete P;
+    efm::set_error("pred_create: hipStreamCreate failed");
+    return EFM_E_LAUNCH;
+  }
+  P->x_nchw = P->alloc<float>((size_t)P->batch * P->c * P->h * P->w);
+  P->x_nhwc = P->alloc<float>((size_t)P->batch * P->h * P->w * efm_pad4(P->c));
+  if (!P->x_nchw || !P->x_nhwc || !build_efm29(*P, params) || hipStreamSynchronize(P->stream) != hipSuccess) {
+    delete P;
+    return EFM_E_INVALID;
+  }
+  *out = P;
+  return EFM_OK;
+}
+
+int efm_pred_set_input(void* handle, const char* key, const float* data, uint32_t size) {
+  Predictor* P = (Predictor*)handle;
+  EFM_REQUIRE(P && key && data && std::string(key) == "data", "pred_set_input: bad argument");
+  EFM_REQUIRE(size == (uint32_t)((size_t)P->batch * P->c * P->h * P->w), "pred_set_input: size %u does not match the bound shape", size);
+  if (hipMemcpyAsync(P->x_nchw, data, (size_t)size * 4, hipMemcpyHostToDevice, P->stream) != hipSuccess) return EFM_E_LAUNCH;
+  return EFM_OK;
+}
+
+int efm_pred_forward(void* handle) {
+  Predictor* P = (Predictor*)handle;
+  EFM_REQUIRE(P, "pred_forward: null handle");
+  int rc = efm_nchw_to_nhwc(P->x_nchw, P->x_nhwc, P->batch, P->c, P->h, P->w, P->stream);
+  for (size_t i = 0; rc == EFM_OK && i < P->ops.size(); ++i) {
+    const Op& op = P->ops[i];
+    if (op.kind == 0)
+      rc = efm_conv_fwd(&op.d, op.in, op.w, op.bias, op.res, op.out, P->stream);
+    else if (op.kind == 1)
+      rc = efm_conv_mfm_fwd(&op.d, op.in, op.w, op.bias, op.out, op.route, op.ways, op.order, op.pool, P->stream);
+    else
+      rc = efm_mfm_fwd(op.in, op.out, op.rows, op.c, 3, P->stream);
+  }
+  return rc;
+}
+
+int efm_pred_get_output_shape(void* handle, uint32_t index, uint32_t** shape_data, uint32_t* shape_ndim) {
+  Predictor* P = (Predictor*)handle;
+  EFM_REQUIRE(P && index == 0 && shape_data && shape_ndim, "pred_get_output_shape: bad argument (one output: the feature)");
+  *shape_data = P->out_shape;
+  *shape_ndim = 2;
+  return EFM_OK;
+}
+
+int efm_pred_get_output(void* handle, uint32_t index, float* data, uint32_t size) {
+  Predictor* P = (Predictor*)handle;
+  EFM_REQUIRE(P && index == 0 && data && size == (uint32_t)(P->batch * P->feat), "pred_get_output: bad argument");
+  const int cp = efm_pad4(P->feat);
+  if (hipMemcpy2DAsync(data, (size_t)P->feat * 4, P->feat_dev, (size_t)cp * 4, (size_t)P->feat * 4, P->batch, hipMemcpyDeviceToHost,
+                       P->stream) != hipSuccess)
+    return EFM_E_LAUNCH;
+  return hipStreamSynchronize(P->stream) == hipSuccess ? EFM_OK : EFM_E_LAUNCH;  // blocking, like MXPredGetOutput
+}
+
+int efm_pred_free(void* handle) {
+  delete (Predictor*)handle;
+  return EFM_OK;
+}
+
+}  // extern "C"

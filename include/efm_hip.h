@@ -191,6 +191,23 @@ int efm_sgd_update(float* w, const float* g, int64_t n, float lr, float wd, floa
 int efm_adam_update(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float eps, float wd, float rescale, int step, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Predictor with the call shape of MXNet's c_predict_api — the consumer side the reference's deployment code uses
+ * (ref: feature_extraction/c_version/Feature.hpp:163-205: MXPredCreatePartialOut / MXPredSetInput / MXPredForward /
+ * MXPredGetOutputShape / MXPredGetOutput / MXPredFree).  Network = Symbol EFM-29 (efm_symbol.py:22-101), output 0 = the
+ * 342-d 'concat29_output' feature (Feature.hpp:24).  param_bytes = contents of an MXNet `.params` file (float32).
+ * symbol_json is accepted and ignored (the structure is fixed).  Host pointers in, host pointers out, blocking
+ * get_output; a predictor owns its device buffers and its stream; one predictor per thread.
+ * ------------------------------------------------------------------------------------ */
+int efm_pred_create(const char* symbol_json, const void* param_bytes, int param_size, int dev_id, uint32_t num_input_nodes,
+                    const char** input_keys, const uint32_t* input_shape_indptr, const uint32_t* input_shape_data,
+                    void** out);
+int efm_pred_set_input(void* handle, const char* key, const float* data, uint32_t size);
+int efm_pred_forward(void* handle);
+int efm_pred_get_output_shape(void* handle, uint32_t index, uint32_t** shape_data, uint32_t* shape_ndim);
+int efm_pred_get_output(void* handle, uint32_t index, float* data, uint32_t size);
+int efm_pred_free(void* handle);
+
 #ifdef __cplusplus
 }
 #endif
