@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE: 256)")
     ap.add_argument("--image", type=int, default=112)
+    ap.add_argument("--workload", choices=["efm", "lightcnn9"], default="efm",
+                    help="efm = BASELINE configs[1] (default, the headline); lightcnn9 = configs[2] geometry in fp32 with in-batch "
+                         "semi-hard mining (every image an anchor) — a secondary line, not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
@@ -144,14 +147,27 @@ def main():
     from improving_face_recognition_performance_using_triplet_loss_amd import synth
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
 
-    tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
-                        n_buckets=int(os.environ.get("EFM_BUCKETS", "6")))
-    labels = synth.parity_labels(args.batch, rank=rank)
-    batches = []
-    for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step
-        x = synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device)
-        neg = synth.negative_indices(labels, 77 + 1000 * rank + s).to(device)
-        batches.append((x, neg))
+    flop_per_image = FLOP_PER_IMAGE_STEP
+    if args.workload == "lightcnn9":
+        from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
+        from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
+        flop_per_image = 4667572224  # 3*fwd - dgrad(conv1), LightCNN-9 @112
+        tr = MiningTripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
+                                  outputs=efm_symbol.lightcnn9_embedding_net())
+        ids = (torch.arange(args.batch) // 4) + rank * (args.batch // 4)  # P = B/4 identities x K = 4 images
+        tr.set_labels(ids)
+        batches = [(synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device), None) for s in range(2)]
+        triplets_per_step = args.batch
+    else:
+        tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
+                            n_buckets=int(os.environ.get("EFM_BUCKETS", "6")))
+        labels = synth.parity_labels(args.batch, rank=rank)
+        batches = []
+        for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step
+            x = synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device)
+            neg = synth.negative_indices(labels, 77 + 1000 * rank + s).to(device)
+            batches.append((x, neg))
+        triplets_per_step = args.batch // 2
 
     for i in range(args.warmup):
         tr.step(*batches[i % 2])
@@ -175,8 +191,8 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        triplets = world * (args.batch // 2) * args.steps / dt
-        images = 2 * triplets
+        triplets = world * triplets_per_step * args.steps / dt
+        images = world * args.batch * args.steps / dt
         out = {
             "metric": baseline_metric(), "value": round(triplets, 2), "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -185,11 +201,16 @@ def main():
                                    "fwd+bwd+SGD, reference batch layout (1 triplet per anchor)" % (args.batch, args.image, args.image),
                        "images_per_gpu": args.batch, "parallelism": "dp%d" % world},
             "images_per_s": round(images, 1),
-            "step_mfma_roofline_frac": round(images / world * FLOP_PER_IMAGE_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "step_mfma_roofline_frac": round(images / world * flop_per_image / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "loss": round(loss_mean, 6),
         }
-        out["roofline"] = dominant_kernel_roofline(tr, torch)
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload == "lightcnn9":
+            out["metric"] = "triplets/sec LightCNN-9 256-d 112x112, in-batch semi-hard mining, fp32 (secondary; BASELINE configs[2] asks bf16)"
+            out["config"] = {"workload": "LightCNN-9 (MFM2), %d images/GPU, every image an anchor, semi-hard negatives mined on device" % args.batch,
+                             "images_per_gpu": args.batch, "parallelism": "dp%d" % world}
+        else:
+            out["roofline"] = dominant_kernel_roofline(tr, torch)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "efm":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.image, torch)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -62,6 +62,7 @@ SIGNATURES = {
     "efm_triplet_indexed_bwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     "efm_cosine_pairs": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "efm_pair_distance": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "efm_gallery_scores": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p]),
     "efm_gram_cosine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "efm_mine_semihard": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "efm_pred_create": (c_int, [c_char_p, c_void_p, c_int, c_int, ctypes.c_uint32, POINTER(c_char_p), POINTER(ctypes.c_uint32),

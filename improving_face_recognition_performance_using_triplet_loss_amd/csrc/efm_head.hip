@@ -233,6 +233,25 @@ __global__ void __launch_bounds__(256) pair_distance_k(const float* __restrict__
   }
 }
 
+// scores[q][i] = <query_q, gallery_i>: the gallery scan of the deployment code (simd_dot over unit-norm 342-d features,
+// ref: Feature.hpp:273-293,345-392), one wave per (gallery row, query), queries staged in LDS.
+__global__ void __launch_bounds__(256) gallery_scores_k(const float* __restrict__ query, const float* __restrict__ gallery,
+                                                        float* __restrict__ scores, int nq, int n, int d, int ldq, int ldg) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = threadIdx.x; k < nq * d; k += 256) qs[k] = query[(long)(k / d) * ldq + (k % d)];
+  __syncthreads();
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= n) return;
+  const float* gr = gallery + (long)row * ldg;
+  for (int q = 0; q < nq; ++q) {
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s = fmaf(qs[q * d + k], gr[k], s);
+    s = wave_sum(s);
+    if (lane == 0) scores[(long)q * n + row] = s;
+  }
+}
+
 // g[i][j] = <e_i, e_j> / (|e_i||e_j|).  Block = row i (4 waves), e_i staged in LDS; each wave walks
 // columns j = wave, wave+4, ...; a lane-strided dot + shuffle reduction per pair.
 __global__ void __launch_bounds__(256) gram_cosine_k(const float* __restrict__ e, float* __restrict__ g, int rows,
@@ -394,6 +413,13 @@ int efm_pair_distance(const float* a, const float* b, const float* mean, float* 
   EFM_REQUIRE(a && b && sqdist && cosine && rows > 0 && d > 0, "pair_distance: bad argument");
   hipLaunchKernelGGL(pair_distance_k, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b, mean, sqdist, cosine, rows, d, lda, ldb);
   return efm::check_launch("pair_distance");
+}
+
+int efm_gallery_scores(const float* query, const float* gallery, float* scores, int nq, int n, int d, int ldq, int ldg, void* stream) {
+  EFM_REQUIRE(query && gallery && scores && nq > 0 && n > 0 && d > 0 && (long)nq * d * 4 <= 64 * 1024, "gallery_scores: bad argument");
+  hipLaunchKernelGGL(gallery_scores_k, dim3((n + 3) / 4), dim3(256), (size_t)nq * d * sizeof(float), (hipStream_t)stream, query, gallery, scores,
+                     nq, n, d, ldq, ldg);
+  return efm::check_launch("gallery_scores");
 }
 
 int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream) {

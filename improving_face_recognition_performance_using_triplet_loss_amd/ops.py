@@ -313,6 +313,18 @@ def pair_distance(a, b, mean=None):
     return sq, cs
 
 
+def gallery_match(query, gallery, topk=1):
+    """Scores of every query against every gallery row + the top-k matches (ref: Feature.hpp:345-392 keeps the best
+    `sim_th`-passing rows).  Returns (scores (nq, n), top values (nq, k), top indices (nq, k))."""
+    _need_rows(query, gallery)
+    nq, d = query.shape
+    n = gallery.shape[0]
+    scores = torch.empty((nq, n), dtype=torch.float32, device=query.device)
+    check(_lib.load().efm_gallery_scores(_p(query), _p(gallery), _p(scores), nq, n, d, _ld(query), _ld(gallery), _stream()), "efm_gallery_scores")
+    vals, idx = torch.topk(scores, min(topk, n), dim=1)  # selection only; the arithmetic is the kernel's
+    return scores, vals, idx
+
+
 def gram_cosine(e):
     _need_rows(e)
     rows, d = e.shape

@@ -173,6 +173,9 @@ int efm_cosine_pairs(const float* a, const float* p, const float* n, float* s_ap
  * cosine[i] = <a_i - mean, b_i - mean> / (|a_i - mean| |b_i - mean|).  `mean` is a [d] vector or NULL. */
 int efm_pair_distance(const float* a, const float* b, const float* mean, float* sqdist, float* cosine, int rows, int d,
                       int lda, int ldb, void* stream);
+/* Gallery scan of the deployment side: scores[q][i] = <query_q, gallery_i> (cosine for unit-norm features) — the batched
+ * form of simd_dot + the per-row loop of Compare_Face_From_DB (ref: Feature.hpp:273-293,345-392).  nq*d*4 <= 64 KiB. */
+int efm_gallery_scores(const float* query, const float* gallery, float* scores, int nq, int n, int d, int ldq, int ldg, void* stream);
 /* g[i][j] = cos(e_i, e_j): the batch-all-pairs cosine matrix (north_star mining path; no reference). */
 int efm_gram_cosine(const float* e, float* g, int rows, int d, int lde, void* stream);
 /* Semi-hard negative per (anchor i, positive pos[i]) from the cosine matrix g[rows][rows]:

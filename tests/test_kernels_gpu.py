@@ -282,3 +282,12 @@ def test_conv_mfm_pool_fused(ops, case):
         dyu = ops.mfm_bwd(y, dmf, cout, ways, order)
         assert torch.equal(dyf, dyu)
         assert not torch.isnan(dyf).any() and dy.shape == dyf.shape
+
+
+def test_gallery_scores(ops):
+    g = rand((1000, 342), 41)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    q = g[[17, 900]] + 0.01 * rand((2, 342), 42)
+    scores, vals, idx = ops.gallery_match(dev(q), dev(g), topk=3)
+    assert rel_err(scores.cpu().numpy(), q @ g.T) < 1e-5
+    assert idx[:, 0].tolist() == [17, 900]

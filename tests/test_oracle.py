@@ -229,3 +229,11 @@ def test_oracle_reproduces_mini_efm_golden():
     assert np.allclose(loss, z["loss"], rtol=1e-12) and np.allclose(emb, z["emb"], rtol=1e-10, atol=1e-14)
     assert np.allclose(feat, z["feat"], rtol=1e-10, atol=1e-14)
     assert np.allclose(np.array([np.abs(grads[k]).sum() for k in sorted(grads)]), z["grad_abs_sums"], rtol=1e-9)
+
+
+def test_factor_scheduler_module_matches_oracle():
+    from improving_face_recognition_performance_using_triplet_loss_amd.nn import FactorScheduler
+    s = FactorScheduler(step=6, factor=0.88, stop_factor_lr=5e-15)
+    s.base_lr = 2.4e-4
+    for n in (1, 6, 7, 12, 13, 100, 1000):
+        assert math.isclose(s(n), O.factor_scheduler(2.4e-4, n, 6, 0.88, 5e-15), rel_tol=1e-12)
