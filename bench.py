@@ -160,7 +160,7 @@ def main():
         triplets_per_step = args.batch
     else:
         tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
-                            n_buckets=int(os.environ.get("EFM_BUCKETS", "6")))
+                            n_buckets=int(os.environ.get("EFM_BUCKETS", "6")), autotune=os.environ.get("EFM_AUTOTUNE", "1") != "0")
         labels = synth.parity_labels(args.batch, rank=rank)
         batches = []
         for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step

@@ -19,6 +19,8 @@
 //   The data gradient is the same kernel run on dy with tap-flipped, transposed weights.
 //   The weight gradient contracts over pixels: C[n][k] = sum_m dy[m][n] * A[m][k], split over
 //   m into workspace slabs and reduced in a fixed order (bitwise reproducible).
+#include <algorithm>
+
 #include "efm_common.h"
 
 namespace {
@@ -721,7 +723,7 @@ int round_nt(int nt) {
 // Generic forward-type launch: y[m][n] = sum_k A(x)[m][k] w[n][k] + bias[n] + res[m][n]
 int run_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int batch,
             int hin, int win, int cin_p, int hout, int wout, int cout_p, int kh, int kw, int pad_h,
-            int pad_w, int n_pad16, int k_pad, hipStream_t s) {
+            int pad_w, int n_pad16, int k_pad, int tune, hipStream_t s) {
   ConvP p;
   p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
   p.M = batch * hout * wout;
@@ -731,13 +733,15 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
   p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0;
   const int tiles = n_pad16 / 16;
-  const int nblocks = (tiles + 12) / 13;
+  int nblocks = (tiles + 12) / 13;
+  if ((tune >> 4) > nblocks) nblocks = std::min(tune >> 4, tiles);
   const int NT = round_nt((tiles + nblocks - 1) / nblocks);
   p.nblocks = (tiles + NT - 1) / NT;
   // 64-row tiles (52 accumulator registers at NT = 13 -> 4 blocks per CU) measured equal or better than 128-row
   // tiles for NT >= 7; narrow tiles (NT <= 6) amortise the pixel-tile staging better with 128 rows.
   int MT = (NT >= 7) ? 1 : 2;
   if ((long)efm::cdiv(p.M, 128) * p.nblocks < 1024) MT = 1;
+  if ((tune & 15) == 1 || (tune & 15) == 2) MT = tune & 15;
   MT = env_int("EFM_CONV_MT", MT);
   const int BM = 64 * MT;
   const long mblocks = efm::cdiv(p.M, BM);
@@ -829,6 +833,8 @@ int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, i
   d->k_pad = efm_pad16(kh * kw * d->cin_p);
   d->dn_pad16 = efm_pad16(cin);
   d->dk_pad = efm_pad16(kh * kw * d->cout_p);
+  d->tune_fwd = 0;
+  d->tune_dgrad = 0;
   EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 30) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 30),
               "conv_desc_init: tensor exceeds 2^30 elements (4 GiB buffer descriptors)");
   EFM_REQUIRE(d->k_pad < 65536 && d->dk_pad < 65536, "conv_desc_init: K = kh*kw*channels must stay below 65536");
@@ -866,7 +872,7 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
                  const float* residual, float* y, void* stream) {
   EFM_REQUIRE(d && x && w_packed && y, "conv_fwd: null argument");
   return run_fwd(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
-                 d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, (hipStream_t)stream);
+                 d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, d->tune_fwd, (hipStream_t)stream);
 }
 
 int efm_conv_mfm_supported(const efm_conv_desc* d) { return d && round_nt_epi(d->n_pad16 / 16) > 0; }
@@ -915,7 +921,7 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
   EFM_REQUIRE(d && dy && wd_packed && dx, "conv_bwd_data: null argument");
   // full correlation of dy with the flipped kernel: pad' = k - 1 - pad
   return run_fwd(dy, wd_packed, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->hin, d->win, d->cin_p,
-                 d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, (hipStream_t)stream);
+                 d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, d->tune_dgrad, (hipStream_t)stream);
 }
 
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,

@@ -399,6 +399,57 @@ class Plan:
             main.wait_stream(side)
         return dx_input
 
+    def autotune(self, iters=3, verbose=False):
+        """Time the tiling candidates (64/128-pixel tiles x 1..3 channel blocks) of every plain convolution forward and
+        data gradient at this plan's shapes and store the winners in the descriptors (results are bit-identical for every
+        choice).  ~1 s at B = 256; idempotent."""
+        if self.device.type != "cuda":
+            return {}
+        chosen = {}
+
+        def best(run, d, field):
+            cands = [0] + [mt | (ns << 4) for mt in (1, 2) for ns in (1, 2, 3)]
+            times = {}
+            for c in cands:
+                setattr(d, field, c)
+                run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    run()
+                e1.record()
+                e1.synchronize()
+                times[c] = e0.elapsed_time(e1)
+            win = min(times, key=times.get)
+            if times[win] > 0.97 * times[0]:
+                win = 0  # keep the heuristic unless a candidate is clearly better
+            setattr(d, field, win)
+            return win, times
+
+        seen = {}
+        for st in self.steps:
+            if st.op != "conv":
+                continue
+            d = st.desc
+            key = (d.hin, d.win, d.cin, d.cout, d.kh, d.pad_h, st.epi is not None, st.inputs[0].needs_grad)
+            if key in seen:
+                d.tune_fwd, d.tune_dgrad = seen[key]
+                continue
+            x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=self.device)
+            dy = torch.rand((d.batch, d.hout, d.wout, d.cout_p), device=self.device)
+            if st.epi is None:
+                w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
+                y = torch.empty_like(dy)
+                chosen[st.pname + ":fwd"] = best(lambda: ops.conv_fwd(d, x, w, None, out=y), d, "tune_fwd")[0]
+            if st.inputs[0].needs_grad:
+                wd = torch.rand((d.dn_pad16, d.dk_pad), device=self.device)
+                dx = torch.empty_like(x)
+                chosen[st.pname + ":dgrad"] = best(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), d, "tune_dgrad")[0]
+            seen[key] = (d.tune_fwd, d.tune_dgrad)
+        if verbose:
+            print("[efm autotune]", {k: v for k, v in chosen.items() if v})
+        return chosen
+
     def _side_stream(self):
         if self._side is None:
             # a high-priority stream gets a hardware queue of its own even after RCCL has created its streams

@@ -75,6 +75,10 @@ typedef struct efm_conv_desc {
   int32_t k_pad;                     /* row length of the packed weight = efm_pad16(kh*kw*cin_p) */
   int32_t dn_pad16;                  /* rows of the packed dgrad weight = efm_pad16(cin) */
   int32_t dk_pad;                    /* its row length = efm_pad16(kh*kw*cout_p) */
+  /* Optional tiling choice of efm_conv_fwd / efm_conv_bwd_data: 0 = built-in heuristic, else MT | (nsplit << 4) with
+   * MT in {1,2} (64- or 128-pixel tiles) and nsplit = number of channel blocks.  Any choice gives bit-identical results
+   * (the K order of every output element is fixed); the host may time the candidates once and store the winner here. */
+  int32_t tune_fwd, tune_dgrad;
 } efm_conv_desc;
 
 /* Fill every derived field (hout = hin + 2*pad_h - kh + 1, paddings, packed sizes). */
