@@ -44,6 +44,7 @@ struct ConvP {
   // fused MFM (+ 2x2 max pooling) epilogue
   unsigned char* route;  // per output element: slice (and window pixel) the value came from
   int cout, ways, order, pool, hp, wp;
+  int cn;  // fused epilogue with several channel blocks: block nb owns channels [nb*cn, nb*cn + cn) of EVERY slice
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -107,7 +108,17 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   }
   unsigned b_off[PB];
 #pragma unroll
-  for (int j = 0; j < PB; ++j) b_off[j] = (unsigned)(((n0 + lrow + 64 * j) * p.k_pad + kc4) * 4);
+  for (int j = 0; j < PB; ++j) {
+    int n = n0 + lrow + 64 * j;
+    if (EPI == 1) {
+      // tile column r <-> slice r / cnb, channel cb + r % cnb: every slice of a channel lands in this block, whatever the
+      // number of channel blocks (the weight rows are permuted on the fly, the packed layout stays natural)
+      const int csl = p.cout / p.ways, cb = nb * p.cn, cnb = min(p.cn, csl - cb);
+      const int r = lrow + 64 * j, sl = r / cnb;
+      n = (sl < p.ways) ? sl * csl + cb + (r - sl * cnb) : p.n_pad16;  // beyond the last slice: out of range -> zeros
+    }
+    b_off[j] = (n < p.n_pad16) ? (unsigned)((n * p.k_pad + kc4) * 4) : EFM_OOB;
+  }
   const int taps = p.kh * p.kw;
 
   u32x4 ra[MT], rb[PB];
@@ -134,7 +145,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
       for (int j = 0; j < PB; ++j)
         if (64 * j + 16 * wave < BN)  // wave-uniform: a wave stages 16 whole rows
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(Bs + (64 * j + 16 * wave) * 16),
-                                                   16, b_off[j] + (unsigned)(t * 64), 0, 0, 0);
+                                                   16, b_off[j] == EFM_OOB ? EFM_OOB : b_off[j] + (unsigned)(t * 64), 0, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < MT; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, a_offset(t, j, kh_, kw_, doff, tap_ok), 0, 0);
@@ -232,6 +243,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   const int ways = p.ways, cs = p.cout / ways;
   const int co = (ways == 3) ? 2 * cs : cs;   // real output channels
   const int cpo = (co + 3) & ~3;              // channel stride of z and of the route bytes
+  const int cb = nb * p.cn, cnb = min(p.cn, cs - cb);  // this block's channels [cb, cb + cnb) of every slice
   auto slice3 = [&](float x0, float x1, float x2, float& vmax, int& imax, float& vmin, int& imin) {
     // MXNet: maximum/minimum(lhs, rhs) backward sends a tie to lhs; ORDER_GROUP = max(max(s0,s1),s2), ORDER_RES = max(s2, max(s0,s1))
     imax = (x0 >= x1) ? 0 : 1;
@@ -258,7 +270,8 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int n = nt * 16 + fi;
-          const float bv = (p.bias && n < p.n_pad16) ? p.bias[n] : 0.f;
+          const int sl = n / cnb;
+          const float bv = (p.bias && sl < ways) ? p.bias[sl * cs + cb + (n - sl * cnb)] : 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) Es[(rr + r) * ES + n] = acc[mt][nt][r] + bv;
         }
@@ -272,7 +285,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
           const int m = row0 + 4 * wnd;
           if (m < p.M) {
             const long q = m >> 2;  // pooled output pixel (b, hp, wp), linear
-            for (int c = lane; c < cs; c += 64) {
+            for (int c = lane; c < cnb; c += 64) {
               float bmax = 0.f, bmin = 0.f;
               int rmax = 0, rmin = 0;
 #pragma unroll
@@ -281,23 +294,23 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
                 float vmax, vmin = 0.f;
                 int imax, imin = 0;
                 if (ways == 3) {
-                  slice3(e[c], e[cs + c], e[2 * cs + c], vmax, imax, vmin, imin);
+                  slice3(e[c], e[cnb + c], e[2 * cnb + c], vmax, imax, vmin, imin);
                 } else {
-                  const float x0 = e[c], x1 = e[cs + c];
+                  const float x0 = e[c], x1 = e[cnb + c];
                   imax = (x0 >= x1) ? 0 : 1;
                   vmax = fmaxf(x0, x1);
                 }
                 if (j == 0 || vmax > bmax) { bmax = vmax; rmax = j * 4 + imax; }   // first maximum of the window wins
                 if (j == 0 || vmin > bmin) { bmin = vmin; rmin = j * 4 + imin; }
               }
-              p.y[q * cpo + c] = bmax;
-              p.route[q * cpo + c] = (unsigned char)rmax;
+              p.y[q * cpo + cb + c] = bmax;
+              p.route[q * cpo + cb + c] = (unsigned char)rmax;
               if (ways == 3) {
-                p.y[q * cpo + cs + c] = bmin;
-                p.route[q * cpo + cs + c] = (unsigned char)rmin;
+                p.y[q * cpo + cs + cb + c] = bmin;
+                p.route[q * cpo + cs + cb + c] = (unsigned char)rmin;
               }
             }
-            if (lane < cpo - co) p.y[q * cpo + co + lane] = 0.f;
+            if (nb == 0 && lane < cpo - co) p.y[q * cpo + co + lane] = 0.f;
           }
         }
       } else {
@@ -305,22 +318,22 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
           const long m = row0 + row;
           if (m < p.M) {
             const float* e = Es + row * ES;
-            for (int c = lane; c < cs; c += 64) {
+            for (int c = lane; c < cnb; c += 64) {
               if (ways == 3) {
                 float vmax, vmin;
                 int imax, imin;
-                slice3(e[c], e[cs + c], e[2 * cs + c], vmax, imax, vmin, imin);
-                p.y[m * cpo + c] = vmax;
-                p.y[m * cpo + cs + c] = vmin;
-                p.route[m * cpo + c] = (unsigned char)imax;
-                p.route[m * cpo + cs + c] = (unsigned char)imin;
+                slice3(e[c], e[cnb + c], e[2 * cnb + c], vmax, imax, vmin, imin);
+                p.y[m * cpo + cb + c] = vmax;
+                p.y[m * cpo + cs + cb + c] = vmin;
+                p.route[m * cpo + cb + c] = (unsigned char)imax;
+                p.route[m * cpo + cs + cb + c] = (unsigned char)imin;
               } else {
-                const float x0 = e[c], x1 = e[cs + c];
-                p.y[m * cpo + c] = fmaxf(x0, x1);
-                p.route[m * cpo + c] = (unsigned char)((x0 >= x1) ? 0 : 1);
+                const float x0 = e[c], x1 = e[cnb + c];
+                p.y[m * cpo + cb + c] = fmaxf(x0, x1);
+                p.route[m * cpo + cb + c] = (unsigned char)((x0 >= x1) ? 0 : 1);
               }
             }
-            if (lane < cpo - co) p.y[m * cpo + co + lane] = 0.f;
+            if (nb == 0 && lane < cpo - co) p.y[m * cpo + co + lane] = 0.f;
           }
         }
       }
@@ -731,7 +744,7 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   p.hout = hout; p.wout = wout; p.cout_p = cout_p;
   p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
   p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
-  p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0;
+  p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0;
   const int tiles = n_pad16 / 16;
   int nblocks = (tiles + 12) / 13;
   if ((tune >> 4) > nblocks) nblocks = std::min(tune >> 4, tiles);
@@ -875,7 +888,7 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
                  d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, d->tune_fwd, (hipStream_t)stream);
 }
 
-int efm_conv_mfm_supported(const efm_conv_desc* d) { return d && round_nt_epi(d->n_pad16 / 16) > 0; }
+int efm_conv_mfm_supported(const efm_conv_desc* d) { return d != nullptr; }
 
 int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
                      unsigned char* route, int ways, int order, int pool, void* stream) {
@@ -883,15 +896,30 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
   EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
-  const int NT = round_nt_epi(d->n_pad16 / 16);
-  EFM_REQUIRE(NT > 0, "conv_mfm_fwd: %d output channels exceed one channel block", d->cout);
+  // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default: as few as fit NT <= 13 at small
+  // maps (more, smaller tiles fill 256 CUs better when there are < 4 pixel tiles per CU), one block otherwise.
+  const int cs_all = d->cout / ways;
+  int nsplit = d->tune_fwd >> 4;
+  if (nsplit <= 0) nsplit = ((long)d->batch * d->hout * d->wout <= 65536 && ways * cs_all > 13 * 16) ? 2 : 1;
+  nsplit = std::min(nsplit, cs_all);
+  int cn = (cs_all + nsplit - 1) / nsplit;
+  nsplit = (cs_all + cn - 1) / cn;
+  int NT = round_nt_epi((ways * cn + 15) / 16);
+  while (NT < 0 && cn > 1) {  // too wide for one block: split further
+    ++nsplit;
+    cn = (cs_all + nsplit - 1) / nsplit;
+    nsplit = (cs_all + cn - 1) / cn;
+    NT = round_nt_epi((ways * cn + 15) / 16);
+  }
+  EFM_REQUIRE(NT > 0, "conv_mfm_fwd: no tiling for %d output channels", d->cout);
   ConvP p;
   p.x = x; p.w = w_packed; p.bias = bias; p.res = nullptr; p.y = z;
   p.hin = d->hin; p.win = d->win; p.cin_p = d->cin_p;
   p.hout = d->hout; p.wout = d->wout; p.cout_p = d->cout_p;
   p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad; p.ksteps = d->k_pad / 16;
-  p.nblocks = 1;
+  p.nblocks = nsplit;
+  p.cn = cn;
   p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
   p.hp = d->hout / 2; p.wp = d->wout / 2;
   p.M = pool ? d->batch * p.hp * p.wp * 4 : d->batch * d->hout * d->wout;
@@ -899,7 +927,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)d->kw - 1) / (unsigned)d->kw);
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
-  dim3 grid((unsigned)efm::cdiv(p.M, 64));
+  dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
   int rc = launch_fwd_epi(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_mfm_fwd");

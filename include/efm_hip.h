@@ -104,7 +104,8 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
  * (ref: efm_symbol.py:32-39, 54-60, 65-78).  z: [batch][h'][w'][pad4(c')] with c' = 2*cout/3 (ways 3) or cout/2 (ways 2)
  * and (h', w') = (hout/2, wout/2) when pool else (hout, wout).  route: one byte per element of z (same shape) recording the
  * slice (and, with pooling, the window pixel: 4*pixel + slice) the value came from, with MXNet's tie rules.
- * Needs every slice of a channel in one channel block: efm_conv_mfm_supported(d) != 0  (cout <= 400). */
+ * Wide layers are cut into channel blocks that each own a channel range of EVERY slice (weight rows permuted on the fly;
+ * number of blocks = d->tune_fwd >> 4, 0 = heuristic), so any cout is supported: efm_conv_mfm_supported(d) != 0. */
 int efm_conv_mfm_supported(const efm_conv_desc* d);
 int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
                      unsigned char* route, int ways, int order, int pool, void* stream);

@@ -196,7 +196,7 @@ def test_fused_plan_is_bitwise_equal_to_unfused():
     res = []
     for fuse in (True, False):
         tr = TripletTrainer(8, image=112, seed=5, fuse=fuse)
-        assert (tr.plan.fused == 19) if fuse else (tr.plan.fused == 0)
+        assert (tr.plan.fused == 20) if fuse else (tr.plan.fused == 0)
         x = synth.images(8, 3, 112, 21)
         neg = synth.negative_indices(synth.parity_labels(8, images_per_identity=2), 9).cuda()
         loss = tr.forward_loss(x, neg).clone()

@@ -16,7 +16,7 @@ from oracle import efm_oracle as O
 
 def test_plan_lowering_matches_reference_structure():
     fused = Plan(efm_symbol.embedding_net(), (256, 3, 112, 112), device="cpu")
-    assert fused.fused == 19 and len([s for s in fused.steps if s.op == "mfm"]) == 11 and not [s for s in fused.steps if s.op == "pool"]
+    assert fused.fused == 20 and len([s for s in fused.steps if s.op == "mfm"]) == 10 and not [s for s in fused.steps if s.op == "pool"]
     assert [s.shape for s in fused.steps if s.op == "conv" and s.epi and s.epi["pool"]] == \
         [(66, 56, 56), (132, 28, 28), (258, 14, 14), (174, 7, 7), (174, 3, 3)]
     plan = Plan(efm_symbol.embedding_net(), (256, 3, 112, 112), device="cpu", fuse=False)

@@ -244,6 +244,7 @@ FUSED_CASES = [
     (2, 5, 5, 258, 387, 1, 0, 3, False),   # conv_r 1x1
     (2, 10, 8, 3, 96, 5, 2, 2, True),      # LightCNN-style MFM2 + pool
     (1, 6, 6, 48, 80, 3, 1, 2, False),     # MFM2, NT rounds 5 -> 5
+    (2, 3, 3, 64, 513, 3, 0, 3, False),    # fc1-like: 513 channels -> several channel blocks
 ]
 
 
@@ -266,8 +267,10 @@ def test_conv_mfm_pool_fused(ops, case):
     if pool:
         z_ref = O.maxpool2(z_ref)
     co = z_ref.shape[1]
-    for order in (O.ORDER_GROUP, O.ORDER_RES):
+    for order, nsplit in ((O.ORDER_GROUP, 0), (O.ORDER_RES, 0), (O.ORDER_GROUP, 2), (O.ORDER_RES, 3)):
+        d.tune_fwd = nsplit << 4  # channel blocks: 0 = heuristic
         z, route = ops.conv_mfm_fwd(d, xd, wp, bp, ways, order, pool)
+        d.tune_fwd = 0
         assert rel_err(from_nhwc(z, co), z_ref) < TOL
         # unfused chain on the device
         y = ops.conv_fwd(d, xd, wp, bp)
@@ -276,12 +279,11 @@ def test_conv_mfm_pool_fused(ops, case):
         assert torch.equal(z, zu)
         dz = rand(z_ref.shape, 34)
         dzd = to_nhwc(dz)
-        dy = torch.full((b, h, w, d.cout_p), float("nan"), device="cuda")
         dyf = ops.mfm_pool_bwd(d, route, dzd, ways, pool)
         dmf = ops.maxpool2_bwd(mf, dzd, co) if pool else dzd
         dyu = ops.mfm_bwd(y, dmf, cout, ways, order)
         assert torch.equal(dyf, dyu)
-        assert not torch.isnan(dyf).any() and dy.shape == dyf.shape
+        assert not torch.isnan(dyf).any() and tuple(dyf.shape) == (b, d.hout, d.wout, d.cout_p)
 
 
 def test_gallery_scores(ops):
