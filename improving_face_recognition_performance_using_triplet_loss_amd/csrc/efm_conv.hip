@@ -896,11 +896,11 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
   EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
-  // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default: as few as fit NT <= 13 at small
-  // maps (more, smaller tiles fill 256 CUs better when there are < 4 pixel tiles per CU), one block otherwise.
+  // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default (measured on EFM-29): one block up
+  // to 13 column tiles, two above (387- and 261-channel layers: 13- / 9-tile blocks beat one 25- / 17-tile block).
   const int cs_all = d->cout / ways;
-  int nsplit = d->tune_fwd >> 4;
-  if (nsplit <= 0) nsplit = ((long)d->batch * d->hout * d->wout <= 65536 && ways * cs_all > 13 * 16) ? 2 : 1;
+  int nsplit = env_int("EFM_EPI_NSPLIT", d->tune_fwd >> 4);
+  if (nsplit <= 0) nsplit = (ways * cs_all > 13 * 16) ? 2 : 1;
   nsplit = std::min(nsplit, cs_all);
   int cn = (cs_all + nsplit - 1) / nsplit;
   nsplit = (cs_all + cn - 1) / cn;

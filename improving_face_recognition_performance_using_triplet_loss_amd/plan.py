@@ -407,8 +407,8 @@ class Plan:
             return {}
         chosen = {}
 
-        def best(run, d, field):
-            cands = [0] + [mt | (ns << 4) for mt in (1, 2) for ns in (1, 2, 3)]
+        def best(run, d, field, cands=None):
+            cands = cands or ([0] + [mt | (ns << 4) for mt in (1, 2) for ns in (1, 2, 3)])
             times = {}
             for c in cands:
                 setattr(d, field, c)
@@ -441,6 +441,11 @@ class Plan:
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 y = torch.empty_like(dy)
                 chosen[st.pname + ":fwd"] = best(lambda: ops.conv_fwd(d, x, w, None, out=y), d, "tune_fwd")[0]
+            else:  # fused epilogue: number of channel blocks
+                w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
+                e = st.epi
+                chosen[st.pname + ":fused"] = best(lambda: ops.conv_mfm_fwd(d, x, w, None, e["ways"], e["order"], e["pool"]), d,
+                                                   "tune_fwd", [0, 1 << 4, 2 << 4, 3 << 4])[0]
             if st.inputs[0].needs_grad:
                 wd = torch.rand((d.dn_pad16, d.dk_pad), device=self.device)
                 dx = torch.empty_like(x)
