@@ -18,7 +18,9 @@ bench = json.loads(open(os.path.join(src, "bench_line.json")).read().strip().spl
 lines = ["# %s — rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`" % name, "",
          "bench line under the profiler: %.2f ms/step, %.1f triplets/s, dominant-kernel roofline %s" %
          (bench["ms_per_step"], bench["value"], json.dumps(bench["roofline"])), "",
-         "7 steps (2 warm-up + 5 timed) + 7 extra conv2-forward launches of the roofline probe; total GPU kernel time %.1f ms" % (total / 1e6), "",
+         "7 steps (2 warm-up + 5 timed) + 7 extra conv2-forward launches of the roofline probe + the start-up tiling autotune "
+         "(every convolution x up to 7 candidates x 4 launches; EFM_AUTOTUNE=0 skips it); total GPU kernel time %.1f ms "
+         "(weight-gradient and data-gradient kernels overlap on two streams, so per-kernel durations add up to more than wall time)" % (total / 1e6), "",
          "| % | total ms | calls | avg us | kernel |", "|---|---|---|---|---|"]
 for r in rows[:30]:
     lines.append("| %.2f | %.3f | %s | %.1f | `%s` |" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6, r["Calls"],
