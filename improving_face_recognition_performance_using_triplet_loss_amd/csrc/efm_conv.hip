@@ -28,11 +28,11 @@ namespace {
 __host__ __device__ __forceinline__ int swz_g(int b) { return (0x78 >> (2 * b)) & 3; }  // {0,2,3,1}
 
 struct ConvP {
-  const float* x;
-  const float* w;
+  const void* x;  // activations / weights / residual / output are float or __bf16 (template parameter T of the kernel)
+  const void* w;
   const float* bias;
-  const float* res;
-  float* y;
+  const void* res;
+  void* y;
   int M;
   int hin, win, cin_p;
   int hout, wout, cout_p;
@@ -45,7 +45,11 @@ struct ConvP {
   unsigned char* route;  // per output element: slice (and window pixel) the value came from
   int cout, ways, order, pool, hp, wp;
   int cn;  // fused epilogue with several channel blocks: block nb owns channels [nb*cn, nb*cn + cn) of EVERY slice
+  int cpo;      // channel stride of the fused epilogue's output z and of the route bytes
+  int out_f32;  // bf16 kernel only: write the fused epilogue's z as float (the layer that feeds the fp32 head)
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define EFM_OOB 0x80000000u  // a byte offset no tensor reaches: the buffer range check then returns zeros
@@ -56,10 +60,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // K loop, so the compiler is free to schedule the loads among the MFMAs.
 // (The body lives in a __device__ function: the buffer-resource builtins only exist in the device pass, and a
 // __global__ template that names them directly loses its host-side launch stub.)
-template <int MT, int NT, bool DMA, int EPI>
+// T = float : v_mfma_f32_16x16x4_f32, 4 channels per 16-byte piece, K step 16 (4 MFMAs per fragment pair);
+// T = __bf16: v_mfma_f32_16x16x32_bf16, 8 channels per piece, K step 32 (1 MFMA per fragment pair); fp32 accumulate.
+// Either way an LDS row is 64 bytes = one K step of one pixel / output channel, so staging, swizzle and fragment
+// addressing are shared.
+template <typename T, int MT, int NT, bool DMA, int EPI>
 __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   constexpr int BM = MT * 64, BN = NT * 16;
   constexpr int PB = (NT * 64 + 255) / 256;
+  constexpr int EB = sizeof(T), CH = 16 / EB, KS = 4 * CH;
+  constexpr bool BF = (EB == 2);
+  static_assert(DMA || !BF, "the bf16 kernel stages through LDS-DMA only");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -71,13 +82,13 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   const int mb = lid / p.nblocks, nb = lid - mb * p.nblocks;
   const int m0 = mb * BM, n0 = nb * BN;
 
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
 
   // ---- staging coordinates: thread -> row = tid/4 (+64 per pass), LDS slot = tid%4 of that row's 64 bytes.
   // The slot holds K piece kc = slot ^ g(row/4 % 4) (XOR swizzle, see file header).
   const int lrow = tid >> 2, slot = tid & 3;
-  const int kc4 = (slot ^ swz_g((lrow >> 2) & 3)) * 4;
+  const int kc4 = (slot ^ swz_g((lrow >> 2) & 3)) * CH;  // element offset of this thread's piece inside a K step
   int a_hi0[MT], a_wi0[MT], a_base[MT];
   const int hw = p.hout * p.wout;
 #pragma unroll
@@ -117,7 +128,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
       const int r = lrow + 64 * j, sl = r / cnb;
       n = (sl < p.ways) ? sl * csl + cb + (r - sl * cnb) : p.n_pad16;  // beyond the last slice: out of range -> zeros
     }
-    b_off[j] = (n < p.n_pad16) ? (unsigned)((n * p.k_pad + kc4) * 4) : EFM_OOB;
+    b_off[j] = (n < p.n_pad16) ? (unsigned)((n * p.k_pad + kc4) * EB) : EFM_OOB;
   }
   const int taps = p.kh * p.kw;
 
@@ -125,10 +136,10 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   auto a_offset = [&](int t, int j, unsigned kh_, unsigned kw_, int doff, bool tap_ok) -> unsigned {
     const int hi = a_hi0[j] + (int)kh_, wi = a_wi0[j] + (int)kw_;
     const bool v = tap_ok && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
-    return v ? (unsigned)((a_base[j] + doff) * 4) : EFM_OOB;
+    return v ? (unsigned)((a_base[j] + doff) * EB) : EFM_OOB;
   };
   auto load_tile = [&](int t, int buf) {
-    const unsigned k = (unsigned)(t * 16 + kc4);
+    const unsigned k = (unsigned)(t * KS + kc4);
     const unsigned tap = __umulhi(k, p.magic_c);
     const int c = (int)(k - tap * (unsigned)p.cin_p);
     const unsigned kh_ = __umulhi(tap, p.magic_kw), kw_ = tap - kh_ * (unsigned)p.kw;
@@ -175,6 +186,21 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   auto compute = [&](int buf) {
     const float* As = smem + buf * (BM + BN) * 16;
     const float* Bs = As + BM * 16;
+    if constexpr (BF) {
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = wave * (MT * 16) + mt * 16 + fi;
+        a[mt] = *reinterpret_cast<const bf16x8*>(As + (row * 4 + fsw) * 4);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + ((nt * 16 + fi) * 4 + fsw) * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+      }
+      return;
+    }
     f32x4 a[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -224,8 +250,8 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
             if (m < p.M) {
               const long off = (long)m * p.cout_p + n;
               float v = acc[mt][nt][r] + bv;
-              if (p.res) v += p.res[off];
-              p.y[off] = v;
+              if (p.res) v += (float)reinterpret_cast<const T*>(p.res)[off];
+              reinterpret_cast<T*>(p.y)[off] = (T)v;
             }
           }
         }
@@ -242,7 +268,12 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   float* Es = smem + wave * (R * ES);
   const int ways = p.ways, cs = p.cout / ways;
   const int co = (ways == 3) ? 2 * cs : cs;   // real output channels
-  const int cpo = (co + 3) & ~3;              // channel stride of z and of the route bytes
+  const int cpo = p.cpo;                      // channel stride of z and of the route bytes
+  const bool zf32 = !BF || p.out_f32;
+  auto put = [&](long idx, float v) {
+    if (zf32) reinterpret_cast<float*>(p.y)[idx] = v;
+    else reinterpret_cast<__bf16*>(p.y)[idx] = (__bf16)v;
+  };
   const int cb = nb * p.cn, cnb = min(p.cn, cs - cb);  // this block's channels [cb, cb + cnb) of every slice
   auto slice3 = [&](float x0, float x1, float x2, float& vmax, int& imax, float& vmin, int& imin) {
     // MXNet: maximum/minimum(lhs, rhs) backward sends a tie to lhs; ORDER_GROUP = max(max(s0,s1),s2), ORDER_RES = max(s2, max(s0,s1))
@@ -303,14 +334,14 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
                 if (j == 0 || vmax > bmax) { bmax = vmax; rmax = j * 4 + imax; }   // first maximum of the window wins
                 if (j == 0 || vmin > bmin) { bmin = vmin; rmin = j * 4 + imin; }
               }
-              p.y[q * cpo + cb + c] = bmax;
+              put(q * cpo + cb + c, bmax);
               p.route[q * cpo + cb + c] = (unsigned char)rmax;
               if (ways == 3) {
-                p.y[q * cpo + cs + cb + c] = bmin;
+                put(q * cpo + cs + cb + c, bmin);
                 p.route[q * cpo + cs + cb + c] = (unsigned char)rmin;
               }
             }
-            if (nb == 0 && lane < cpo - co) p.y[q * cpo + co + lane] = 0.f;
+            if (nb == 0 && lane < cpo - co) put(q * cpo + co + lane, 0.f);
           }
         }
       } else {
@@ -323,17 +354,17 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
                 float vmax, vmin;
                 int imax, imin;
                 slice3(e[c], e[cnb + c], e[2 * cnb + c], vmax, imax, vmin, imin);
-                p.y[m * cpo + cb + c] = vmax;
-                p.y[m * cpo + cs + cb + c] = vmin;
+                put(m * cpo + cb + c, vmax);
+                put(m * cpo + cs + cb + c, vmin);
                 p.route[m * cpo + cb + c] = (unsigned char)imax;
                 p.route[m * cpo + cs + cb + c] = (unsigned char)imin;
               } else {
                 const float x0 = e[c], x1 = e[cnb + c];
-                p.y[m * cpo + cb + c] = fmaxf(x0, x1);
+                put(m * cpo + cb + c, fmaxf(x0, x1));
                 p.route[m * cpo + cb + c] = (unsigned char)((x0 >= x1) ? 0 : 1);
               }
             }
-            if (nb == 0 && lane < cpo - co) p.y[m * cpo + co + lane] = 0.f;
+            if (nb == 0 && lane < cpo - co) put(m * cpo + co + lane, 0.f);
           }
         }
       }
@@ -343,41 +374,41 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int MT, int NT, bool DMA, int EPI>
+template <typename T, int MT, int NT, bool DMA, int EPI>
 __global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
   // K-loop double buffer, re-used by the fused epilogue as 4 per-wave transposition regions of R rows x (BN + 4)
   __shared__ __attribute__((aligned(16))) float smem[cmax(2 * (MT * 64 + NT * 16) * 16,
                                                             EPI ? 4 * ((NT <= 8) ? 16 : 8) * (NT * 16 + 4) : 0)];
-  conv_fwd_body<MT, NT, DMA, EPI>(p, smem);
+  conv_fwd_body<T, MT, NT, DMA, EPI>(p, smem);
 }
 
 // Backward of the fused MFM (+ pooling) epilogue: scatters dz to the conv-output positions recorded in `route` and
 // writes EVERY element of dy (zeros elsewhere, pad channels, and the odd trailing row / column that floor pooling drops).
 // thread = (window or pixel, channel j); j < cs + pad channels.
-__global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __restrict__ route, const float* __restrict__ dz,
-                                                      float* __restrict__ dy, long items, int h, int w, int c, int ways,
-                                                      int pool, int cw) {
+template <typename TZ, typename TY>
+__global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __restrict__ route, const TZ* __restrict__ dz,
+                                                      TY* __restrict__ dy, long items, int h, int w, int c, int ways,
+                                                      int pool, int cw, int cp, int cpo) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= items * cw) return;
   const long it = i / cw;
   const int j = (int)(i - it * cw);
-  const int cs = c / ways, cp = (c + 3) & ~3;
-  const int co = (ways == 3) ? 2 * cs : cs, cpo = (co + 3) & ~3;
+  const int cs = c / ways;
   if (!pool) {
-    float* d = dy + it * cp;
+    TY* d = dy + it * cp;
     if (j < cs) {
-      const float gmax = dz[it * cpo + j];
+      const float gmax = (float)dz[it * cpo + j];
       const int imax = route[it * cpo + j];
       float o0 = imax == 0 ? gmax : 0.f, o1 = imax == 1 ? gmax : 0.f, o2 = imax == 2 ? gmax : 0.f;
       if (ways == 3) {
-        const float gmin = dz[it * cpo + cs + j];
+        const float gmin = (float)dz[it * cpo + cs + j];
         const int imin = route[it * cpo + cs + j];
         o0 += imin == 0 ? gmin : 0.f; o1 += imin == 1 ? gmin : 0.f; o2 += imin == 2 ? gmin : 0.f;
-        d[2 * cs + j] = o2;
+        d[2 * cs + j] = (TY)o2;
       }
-      d[j] = o0; d[cs + j] = o1;
+      d[j] = (TY)o0; d[cs + j] = (TY)o1;
     } else if (c + (j - cs) < cp) {
-      d[c + (j - cs)] = 0.f;
+      d[c + (j - cs)] = (TY)0.f;
     }
     return;
   }
@@ -392,23 +423,23 @@ __global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __res
   int rmax = -1, rmin = -1;
   if (full && j < cs) {
     const long q = (b * hp + hq) * wp + wq;
-    gmax = dz[q * cpo + j];
+    gmax = (float)dz[q * cpo + j];
     rmax = route[q * cpo + j];
-    if (ways == 3) { gmin = dz[q * cpo + cs + j]; rmin = route[q * cpo + cs + j]; }
+    if (ways == 3) { gmin = (float)dz[q * cpo + cs + j]; rmin = route[q * cpo + cs + j]; }
   }
 #pragma unroll
   for (int px = 0; px < 4; ++px) {
     const int hh = 2 * hq + (px >> 1), ww = 2 * wq + (px & 1);
     if (hh >= h || ww >= w) continue;
-    float* d = dy + ((b * h + hh) * w + ww) * cp;
+    TY* d = dy + ((b * h + hh) * w + ww) * cp;
     if (j < cs) {
       for (int sl = 0; sl < ways; ++sl) {
         float o = (rmax == px * 4 + sl) ? gmax : 0.f;
         if (ways == 3 && rmin == px * 4 + sl) o += gmin;
-        d[sl * cs + j] = o;
+        d[sl * cs + j] = (TY)o;
       }
     } else if (c + (j - cs) < cp) {
-      d[c + (j - cs)] = 0.f;
+      d[c + (j - cs)] = (TY)0.f;
     }
   }
 }
@@ -691,12 +722,12 @@ int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-template <int MT, bool DMA>
+template <typename T, int MT, bool DMA>
 int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<MT, N, DMA, 0>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<T, MT, N, DMA, 0>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
 #undef EFM_CASE
@@ -706,11 +737,12 @@ int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
 }
 
 // fused-epilogue variants: one channel block holds every slice of a channel, 64-row tiles
+template <typename T>
 int launch_fwd_epi(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<1, N, true, 1>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<T, 1, N, true, 1>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(7) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13) EFM_CASE(17) EFM_CASE(25)
 #undef EFM_CASE
@@ -744,7 +776,7 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   p.hout = hout; p.wout = wout; p.cout_p = cout_p;
   p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
   p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
-  p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0;
+  p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0; p.cpo = 0; p.out_f32 = 1;
   const int tiles = n_pad16 / 16;
   int nblocks = (tiles + 12) / 13;
   if ((tune >> 4) > nblocks) nblocks = std::min(tune >> 4, tiles);
@@ -766,9 +798,9 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   const bool dma = env_int("EFM_CONV_DMA", 1) != 0;
   int rc;
   if (dma)
-    rc = (MT == 2) ? launch_fwd_nt<2, true>(NT, grid, s, p) : launch_fwd_nt<1, true>(NT, grid, s, p);
+    rc = (MT == 2) ? launch_fwd_nt<float, 2, true>(NT, grid, s, p) : launch_fwd_nt<float, 1, true>(NT, grid, s, p);
   else
-    rc = (MT == 2) ? launch_fwd_nt<2, false>(NT, grid, s, p) : launch_fwd_nt<1, false>(NT, grid, s, p);
+    rc = (MT == 2) ? launch_fwd_nt<float, 2, false>(NT, grid, s, p) : launch_fwd_nt<float, 1, false>(NT, grid, s, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_fwd");
 }
@@ -920,6 +952,8 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad; p.ksteps = d->k_pad / 16;
   p.nblocks = nsplit;
   p.cn = cn;
+  p.cpo = efm_pad4((ways == 3) ? 2 * cs_all : cs_all);
+  p.out_f32 = 1;
   p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
   p.hp = d->hout / 2; p.wp = d->wout / 2;
   p.M = pool ? d->batch * p.hp * p.wp * 4 : d->batch * d->hout * d->wout;
@@ -928,7 +962,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
   dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
-  int rc = launch_fwd_epi(NT, grid, (hipStream_t)stream, p);
+  int rc = launch_fwd_epi<float>(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_mfm_fwd");
 }
@@ -939,8 +973,9 @@ int efm_mfm_pool_bwd(const unsigned char* route, const float* dz, float* dy, int
   EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfm_pool_bwd: c=%d not divisible by ways=%d", c, ways);
   const int cs = c / ways, cw = cs + (efm_pad4(c) - c);
   const long items = pool ? (long)batch * ((h + 1) / 2) * ((w + 1) / 2) : (long)batch * h * w;
-  hipLaunchKernelGGL(mfm_pool_bwd_k, dim3((unsigned)efm::cdiv(items * cw, 256)), dim3(256), 0, (hipStream_t)stream, route, dz, dy,
-                     items, h, w, c, ways, pool ? 1 : 0, cw);
+  const int co = (ways == 3) ? 2 * cs : cs;
+  hipLaunchKernelGGL((mfm_pool_bwd_k<float, float>), dim3((unsigned)efm::cdiv(items * cw, 256)), dim3(256), 0, (hipStream_t)stream, route,
+                     dz, dy, items, h, w, c, ways, pool ? 1 : 0, cw, efm_pad4(c), efm_pad4(co));
   return efm::check_launch("mfm_pool_bwd");
 }
 
