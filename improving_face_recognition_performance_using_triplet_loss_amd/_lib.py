@@ -47,6 +47,16 @@ SIGNATURES = {
     "efm_mfm_pool_bwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "efm_conv_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
     "efm_conv_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "efm_convb_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_convb_dgrad_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_convb_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_nchw_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_convb_cast_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "efm_convb_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 6),
+    "efm_convb_mfm_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "efm_convb_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
+    "efm_convb_mfm_pool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "efm_convb_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "efm_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_mfm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -766,16 +766,18 @@ int round_nt(int nt) {
 }
 
 // Generic forward-type launch: y[m][n] = sum_k A(x)[m][k] w[n][k] + bias[n] + res[m][n]
-int run_fwd(const float* x, const float* w, const float* bias, const float* res, float* y, int batch,
+template <typename T>
+int run_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, int batch,
             int hin, int win, int cin_p, int hout, int wout, int cout_p, int kh, int kw, int pad_h,
             int pad_w, int n_pad16, int k_pad, int tune, hipStream_t s) {
+  constexpr int KS = 64 / (int)sizeof(T);  // K elements per LDS row / K step
   ConvP p;
   p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
   p.M = batch * hout * wout;
   p.hin = hin; p.win = win; p.cin_p = cin_p;
   p.hout = hout; p.wout = wout; p.cout_p = cout_p;
   p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
-  p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / 16;
+  p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / KS;
   p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0; p.cpo = 0; p.out_f32 = 1;
   const int tiles = n_pad16 / 16;
   int nblocks = (tiles + 12) / 13;
@@ -793,12 +795,12 @@ int run_fwd(const float* x, const float* w, const float* bias, const float* res,
   dim3 grid((unsigned)(mblocks * p.nblocks));
   p.magic_c = (unsigned)((0x100000000ULL + (unsigned)cin_p - 1) / (unsigned)cin_p);
   p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)kw - 1) / (unsigned)kw);
-  p.x_bytes = (unsigned)((size_t)batch * hin * win * cin_p * sizeof(float));
-  p.w_bytes = (unsigned)((size_t)n_pad16 * k_pad * sizeof(float));
-  const bool dma = env_int("EFM_CONV_DMA", 1) != 0;
+  p.x_bytes = (unsigned)((size_t)batch * hin * win * cin_p * sizeof(T));
+  p.w_bytes = (unsigned)((size_t)n_pad16 * k_pad * sizeof(T));
+  const bool dma = sizeof(T) == 2 || env_int("EFM_CONV_DMA", 1) != 0;
   int rc;
   if (dma)
-    rc = (MT == 2) ? launch_fwd_nt<float, 2, true>(NT, grid, s, p) : launch_fwd_nt<float, 1, true>(NT, grid, s, p);
+    rc = (MT == 2) ? launch_fwd_nt<T, 2, true>(NT, grid, s, p) : launch_fwd_nt<T, 1, true>(NT, grid, s, p);
   else
     rc = (MT == 2) ? launch_fwd_nt<float, 2, false>(NT, grid, s, p) : launch_fwd_nt<float, 1, false>(NT, grid, s, p);
   if (rc != EFM_OK) return rc;
@@ -855,6 +857,282 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
   pl.bias_groups = (pl.bias_chunks + 31) / 32;
   pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.bias_chunks + pl.bias_groups) * d->n_pad16;
+  return pl;
+}
+
+
+// ==========================================================================================================
+// bf16 tensor-core path (BASELINE configs[2]): bf16 NHWC activations (channel stride pad8), bf16 packed weights
+// (k = tap*pad8(cin) + ci, row length pad32), fp32 accumulate, fp32 master weights / gradients in the fp32 packed layout.
+// ==========================================================================================================
+__host__ __device__ __forceinline__ int pad8(int c) { return (c + 7) & ~7; }
+__host__ __device__ __forceinline__ int pad32(int c) { return (c + 31) & ~31; }
+
+__global__ void __launch_bounds__(256) nchw_to_nhwc_bf16_k(const float* __restrict__ x, __bf16* __restrict__ y, long pixels,
+                                                           int c, int hw, int cp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ng = cp >> 3;
+  if (i >= pixels * ng) return;
+  const long pix = i / ng;
+  const int g = (int)(i - pix * ng);
+  const long b = pix / hw, r = pix - b * hw;
+  bf16x8 v;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = g * 8 + k;
+    v[k] = (__bf16)((ch < c) ? x[(b * c + ch) * hw + r] : 0.f);
+  }
+  *reinterpret_cast<bf16x8*>(y + pix * cp + g * 8) = v;
+}
+
+// fp32 packed master weight -> bf16 forward weight wb[n][tap*cin_p8 + ci] and bf16 data-gradient weight
+// wdb[ci][flip(tap)*cout_p8 + co]; one thread per destination element of either matrix.
+__global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restrict__ w32, __bf16* __restrict__ wb,
+                                                           __bf16* __restrict__ wdb, efm_conv_desc d, long nf, long nd) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int taps = d.kh * d.kw, cin8 = pad8(d.cin), cout8 = pad8(d.cout);
+  if (i < nf) {
+    const int kp = pad32(taps * cin8);
+    const int n = (int)(i / kp), k = (int)(i - (long)n * kp);
+    const int tap = k / cin8, ci = k - tap * cin8;
+    float v = 0.f;
+    if (n < d.cout && tap < taps && ci < d.cin) v = w32[(long)n * d.k_pad + tap * d.cin_p + ci];
+    wb[i] = (__bf16)v;
+  } else if (i < nf + nd && wdb != nullptr) {
+    const long e = i - nf;
+    const int kp = pad32(taps * cout8);
+    const int ci = (int)(e / kp), k = (int)(e - (long)ci * kp);
+    const int tap = k / cout8, co = k - tap * cout8;
+    float v = 0.f;
+    if (ci < d.cin && tap < taps && co < d.cout) {
+      const int fkh = tap / d.kw, fkw = tap - fkh * d.kw;
+      v = w32[(long)co * d.k_pad + ((d.kh - 1 - fkh) * d.kw + (d.kw - 1 - fkw)) * d.cin_p + ci];
+    }
+    wdb[e] = (__bf16)v;
+  }
+}
+
+// ---- bf16 weight gradient: C[n][k] = sum_pixels dy[pix][n] * A[pix][k], contraction (MFMA K) = 32 pixels per step.
+// The tiles arrive by LDS-DMA as [pixel][channel] rows; the MFMA wants 8 consecutive PIXELS of one channel per lane, i.e. the
+// transposed image: ds_read_b64_tr_b16 delivers exactly that (4 pixels x 16 channels per 16-lane group, column-major).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradBP {
+  const __bf16* x;
+  const __bf16* dy;
+  float* ws;         // slabs [split][n_pad16][kb_pad]
+  float* bias_part;  // [chunks][n_pad16] or nullptr
+  int M, hin, win, cin_p, hout, wout, cout_p, kh, kw, pad_h, pad_w;
+  int n_pad16, kb_pad;
+  int kblocks, nblocks, splits, m_per_split, mma_blocks;
+  unsigned x_bytes, y_bytes;
+};
+
+template <int KPW, int NTW>
+__device__ __forceinline__ void convb_wgrad_body(const WgradBP& p, __bf16* smem) {
+  constexpr int BKR = 64 * KPW, BNW = 16 * NTW, BP = 32;
+  constexpr int K8 = BKR / 8, N8 = BNW / 8;          // 16-byte pieces per pixel row
+  constexpr int PX = (BP * K8 + 255) / 256, PY = (BP * N8 + 255) / 256;
+  constexpr int TILE = BP * (BKR + BNW);              // bf16 elements per stage
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tiles = p.kblocks * p.nblocks;
+  const int split = bid / tiles;
+  bid -= split * tiles;
+  const int kb = bid / p.nblocks, nb = bid - kb * p.nblocks;
+  const int k0 = kb * BKR, n0 = nb * BNW;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int hw = p.hout * p.wout;
+  const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.wout;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dy), 0, p.y_bytes, 0x00020000);
+  const int taps = p.kh * p.kw;
+
+  auto load_tile = [&](int step, int buf) {
+    __bf16* Xs = smem + buf * TILE;
+    __bf16* Ys = Xs + BP * BKR;
+    const int mbase = m_begin + step * BP;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      if (256 * j + 64 * wave < BP * K8) {  // wave-uniform
+        const int e = tid + 256 * j;
+        const int pp = e / K8, piece = e - pp * K8;
+        const int kg = k0 + piece * 8;
+        const int tap = kg / p.cin_p, c = kg - tap * p.cin_p;
+        const int tkh = tap / p.kw, tkw = tap - tkh * p.kw;
+        const int m = mbase + pp;
+        const int b = fdiv(m, hw, inv_hw), r = m - b * hw;
+        const int ho = fdiv(r, p.wout, inv_w), wo = r - ho * p.wout;
+        const int hi = ho - p.pad_h + tkh, wi = wo - p.pad_w + tkw;
+        const bool v = tap < taps && m < m_end && (unsigned)hi < (unsigned)p.hin && (unsigned)wi < (unsigned)p.win;
+        const unsigned off = v ? (unsigned)((((b * p.hin + hi) * p.win + wi) * p.cin_p + c) * 2) : EFM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(Xs + (256 * j + 64 * wave) * 8), 16, off, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PY; ++j) {
+      if (256 * j + 64 * wave < BP * N8) {
+        const int e = tid + 256 * j;
+        const int pp = e / N8, piece = e - pp * N8;
+        const int m = mbase + pp, n = n0 + piece * 8;
+        const bool v = m < m_end && n < p.cout_p;
+        const unsigned off = v ? (unsigned)((m * p.cout_p + n) * 2) : EFM_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(Ys + (256 * j + 64 * wave) * 8), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[KPW][NTW];
+#pragma unroll
+  for (int a = 0; a < KPW; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment: lane = 16*q + 4*r + c4 supplies the address of pixel row (8q + 4h + r), channels 4*c4..4*c4+3 of the
+  // 16-channel tile; it receives channel (lane & 15)'s 4 pixels.  Two reads (h = 0, 1) = the 8 K values of one MFMA operand.
+  const int fq = lane >> 4, fr = (lane >> 2) & 3, fc4 = lane & 3, fi = lane & 15;
+  auto frag = [&](const __bf16* tile, int row_elems, int ch0) -> bf16x8 {
+    const __bf16* a0 = tile + (8 * fq + fr) * row_elems + ch0 + 4 * fc4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * row_elems));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&](int buf) {
+    const __bf16* Xs = smem + buf * TILE;
+    const __bf16* Ys = Xs + BP * BKR;
+    bf16x8 bx[KPW];
+#pragma unroll
+    for (int kt = 0; kt < KPW; ++kt) bx[kt] = frag(Xs, BKR, (wave * KPW + kt) * 16);
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const bf16x8 ay = frag(Ys, BNW, nt * 16);
+#pragma unroll
+      for (int kt = 0; kt < KPW; ++kt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ay, bx[kt], acc[kt][nt], 0, 0, 0);
+    }
+  };
+
+  const int steps = (m_end - m_begin + BP - 1) / BP;
+  if (steps > 0) load_tile(0, 0);
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    if (t + 1 < steps) load_tile(t + 1, (t + 1) & 1);
+    compute(t & 1);
+    __syncthreads();
+  }
+
+  float* ws = p.ws + (long)split * p.n_pad16 * p.kb_pad;
+  const int rq = lane >> 4;
+#pragma unroll
+  for (int kt = 0; kt < KPW; ++kt) {
+    const int k = k0 + (wave * KPW + kt) * 16 + fi;
+    if (k < p.kb_pad) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + nt * 16 + rq * 4 + r;
+          if (n < p.n_pad16) ws[(long)n * p.kb_pad + k] = acc[kt][nt][r];
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void bias_colsum_bf16_body(const WgradBP& p, float* red, int chunk) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int m_begin = chunk * BIAS_ROWS, m_end = min(p.M, m_begin + BIAS_ROWS);
+  const int ng = p.cout_p >> 2, ng16 = p.n_pad16 >> 2;  // groups of 4 channels (8 bytes of bf16)
+  for (int g0 = 0; g0 < ng16; g0 += 64) {
+    const int g = g0 + cx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (g < ng)
+      for (int m = m_begin + ry; m < m_end; m += 4) {
+        const s16x4 v = *reinterpret_cast<const s16x4*>(p.dy + (long)m * p.cout_p + g * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += __builtin_bit_cast(float, ((unsigned)(unsigned short)v[k]) << 16);
+      }
+    *reinterpret_cast<f32x4*>(red + (ry * 64 + cx) * 4) = s;
+    __syncthreads();
+    if (ry == 0 && g < ng16) {
+      f32x4 t = *reinterpret_cast<f32x4*>(red + cx * 4);
+      t += *reinterpret_cast<f32x4*>(red + (64 + cx) * 4);
+      t += *reinterpret_cast<f32x4*>(red + (128 + cx) * 4);
+      t += *reinterpret_cast<f32x4*>(red + (192 + cx) * 4);
+      *reinterpret_cast<f32x4*>(p.bias_part + (long)chunk * p.n_pad16 + g * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
+template <int KPW, int NTW>
+__global__ void __launch_bounds__(256, 2) convb_wgrad_k(const WgradBP p) {
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 32 * (64 * KPW + 16 * NTW)];
+  if ((int)blockIdx.x >= p.mma_blocks)
+    bias_colsum_bf16_body(p, reinterpret_cast<float*>(smem), (int)blockIdx.x - p.mma_blocks);
+  else
+    convb_wgrad_body<KPW, NTW>(p, smem);
+}
+
+// sum the slabs (bf16 K layout, channel stride cin_p8) into the fp32 packed gradient (channel stride cin_p4)
+__global__ void __launch_bounds__(256) slab_reduce_remap_k(const float* __restrict__ ws, float* __restrict__ out, efm_conv_desc d,
+                                                           int kb_pad, int splits, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)d.n_pad16 * d.k_pad;
+  if (i >= total) return;
+  const int n = (int)(i / d.k_pad), k = (int)(i - (long)n * d.k_pad);
+  const int tap = k / d.cin_p, ci = k - tap * d.cin_p;
+  float s = 0.f;
+  if (tap < d.kh * d.kw) {
+    const long src = (long)n * kb_pad + tap * pad8(d.cin) + ci;
+    const long stride = (long)d.n_pad16 * kb_pad;
+    for (int sp = 0; sp < splits; ++sp) s += ws[sp * stride + src];
+  }
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+template <int KPW>
+int launch_wgradb_nt(int NTW, dim3 grid, hipStream_t s, const WgradBP& p) {
+  switch (NTW) {
+#define EFM_CASE(N)                                              \
+  case N:                                                        \
+    hipLaunchKernelGGL((convb_wgrad_k<KPW, N>), grid, dim3(256), 0, s, p); \
+    return EFM_OK;
+    EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
+#undef EFM_CASE
+  }
+  efm::set_error("convb_wgrad: unsupported NTW=%d", NTW);
+  return EFM_E_INVALID;
+}
+
+struct WgradBPlan {
+  int KPW, NTW, kblocks, nblocks, splits, m_per_split, bias_chunks, kb_pad;
+  size_t slab_floats, ws_floats;
+};
+
+WgradBPlan plan_wgradb(const efm_conv_desc* d) {
+  WgradBPlan pl;
+  const int M = d->batch * d->hout * d->wout;
+  pl.kb_pad = pad32(d->kh * d->kw * pad8(d->cin));
+  const int ktiles = (pl.kb_pad + 15) / 16, ntiles = d->n_pad16 / 16;
+  pl.KPW = (ktiles >= 5) ? 2 : 1;
+  pl.kblocks = (ktiles + 4 * pl.KPW - 1) / (4 * pl.KPW);
+  const int nb = (ntiles + 12) / 13;
+  pl.NTW = round_nt((ntiles + nb - 1) / nb);
+  pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
+  const int base = pl.kblocks * pl.nblocks;
+  int splits = (env_int("EFM_WGRAD_BLOCKS", 2560) + base - 1) / base;
+  const int max_splits = std::min(32, (M + 1023) / 1024);  // the remap reduction walks the slabs serially: keep them few
+  splits = std::max(1, std::min(splits, max_splits));
+  int mps = (M + splits - 1) / splits;
+  mps = (mps + 31) & ~31;
+  pl.m_per_split = mps;
+  pl.splits = (M + mps - 1) / mps;
+  pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
+  pl.slab_floats = (size_t)pl.splits * d->n_pad16 * pl.kb_pad;
+  pl.ws_floats = pl.slab_floats + (size_t)(pl.bias_chunks + (pl.bias_chunks + 31) / 32) * d->n_pad16;
   return pl;
 }
 
@@ -916,7 +1194,7 @@ int efm_conv_make_dgrad_weights(const efm_conv_desc* d, const float* w_packed, f
 int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                  const float* residual, float* y, void* stream) {
   EFM_REQUIRE(d && x && w_packed && y, "conv_fwd: null argument");
-  return run_fwd(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
+  return run_fwd<float>(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
                  d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, d->tune_fwd, (hipStream_t)stream);
 }
 
@@ -983,7 +1261,7 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
                       float* dx, void* stream) {
   EFM_REQUIRE(d && dy && wd_packed && dx, "conv_bwd_data: null argument");
   // full correlation of dy with the flipped kernel: pad' = k - 1 - pad
-  return run_fwd(dy, wd_packed, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->hin, d->win, d->cin_p,
+  return run_fwd<float>(dy, wd_packed, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->hin, d->win, d->cin_p,
                  d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, d->tune_dgrad, (hipStream_t)stream);
 }
 
@@ -1032,6 +1310,146 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   if (rc != EFM_OK) return rc;
   if (dbias) rc = reduce(bpart, bpart2, dbias, d->n_pad16 / 4, pl.bias_chunks);
   return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------- bf16 path
+size_t efm_convb_weight_elems(const efm_conv_desc* d) { return (size_t)d->n_pad16 * pad32(d->kh * d->kw * pad8(d->cin)); }
+size_t efm_convb_dgrad_weight_elems(const efm_conv_desc* d) { return (size_t)d->dn_pad16 * pad32(d->kh * d->kw * pad8(d->cout)); }
+size_t efm_convb_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wgradb(d).ws_floats * sizeof(float); }
+
+int efm_nchw_to_nhwc_bf16(const float* x, uint16_t* y, int batch, int c, int h, int w, void* stream) {
+  EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc_bf16: bad argument");
+  const long pixels = (long)batch * h * w;
+  const int cp = pad8(c);
+  hipLaunchKernelGGL(nchw_to_nhwc_bf16_k, dim3((unsigned)efm::cdiv(pixels * (cp >> 3), 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<__bf16*>(y), pixels, c, h * w, cp);
+  return efm::check_launch("nchw_to_nhwc_bf16");
+}
+
+int efm_convb_cast_weights(const efm_conv_desc* d, const float* w_packed, uint16_t* wb, uint16_t* wdb, void* stream) {
+  EFM_REQUIRE(d && w_packed && wb, "convb_cast_weights: null argument");
+  const long nf = (long)efm_convb_weight_elems(d), nd = wdb ? (long)efm_convb_dgrad_weight_elems(d) : 0;
+  hipLaunchKernelGGL(cast_weights_bf16_k, dim3((unsigned)efm::cdiv(nf + nd, 256)), dim3(256), 0, (hipStream_t)stream, w_packed,
+                     reinterpret_cast<__bf16*>(wb), reinterpret_cast<__bf16*>(wdb), *d, nf, nd);
+  return efm::check_launch("convb_cast_weights");
+}
+
+int efm_convb_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, const uint16_t* residual,
+                  uint16_t* y, void* stream) {
+  EFM_REQUIRE(d && x && wb && y, "convb_fwd: null argument");
+  return run_fwd<__bf16>(x, wb, bias, residual, y, d->batch, d->hin, d->win, pad8(d->cin), d->hout, d->wout, pad8(d->cout), d->kh, d->kw,
+                         d->pad_h, d->pad_w, d->n_pad16, pad32(d->kh * d->kw * pad8(d->cin)), d->tune_fwd, (hipStream_t)stream);
+}
+
+int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_t* wdb, const uint16_t* add, uint16_t* dx, void* stream) {
+  EFM_REQUIRE(d && dy && wdb && dx, "convb_bwd_data: null argument");
+  return run_fwd<__bf16>(dy, wdb, nullptr, add, dx, d->batch, d->hout, d->wout, pad8(d->cout), d->hin, d->win, pad8(d->cin), d->kh, d->kw,
+                         d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, pad32(d->kh * d->kw * pad8(d->cout)), d->tune_dgrad,
+                         (hipStream_t)stream);
+}
+
+int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, void* z, unsigned char* route,
+                      int ways, int order, int pool, int out_f32, void* stream) {
+  EFM_REQUIRE(d && x && wb && z && route, "convb_mfm_fwd: null argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "convb_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "convb_mfm_fwd: bad order %d", order);
+  const int cs_all = d->cout / ways;
+  int nsplit = d->tune_fwd >> 4;
+  if (nsplit <= 0) nsplit = (ways * cs_all > 13 * 16) ? 2 : 1;
+  nsplit = std::min(nsplit, cs_all);
+  int cn = (cs_all + nsplit - 1) / nsplit;
+  nsplit = (cs_all + cn - 1) / cn;
+  int NT = round_nt_epi((ways * cn + 15) / 16);
+  while (NT < 0 && cn > 1) {
+    ++nsplit;
+    cn = (cs_all + nsplit - 1) / nsplit;
+    nsplit = (cs_all + cn - 1) / cn;
+    NT = round_nt_epi((ways * cn + 15) / 16);
+  }
+  EFM_REQUIRE(NT > 0, "convb_mfm_fwd: no tiling for %d output channels", d->cout);
+  const int cin8 = pad8(d->cin), kp = pad32(d->kh * d->kw * cin8), co = (ways == 3) ? 2 * cs_all : cs_all;
+  ConvP p;
+  p.x = x; p.w = wb; p.bias = bias; p.res = nullptr; p.y = z;
+  p.hin = d->hin; p.win = d->win; p.cin_p = cin8;
+  p.hout = d->hout; p.wout = d->wout; p.cout_p = pad8(d->cout);
+  p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.n_pad16 = d->n_pad16; p.k_pad = kp; p.ksteps = kp / 32;
+  p.nblocks = nsplit; p.cn = cn;
+  p.cpo = out_f32 ? efm_pad4(co) : pad8(co);
+  p.out_f32 = out_f32 ? 1 : 0;
+  p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
+  p.hp = d->hout / 2; p.wp = d->wout / 2;
+  p.M = pool ? d->batch * p.hp * p.wp * 4 : d->batch * d->hout * d->wout;
+  p.magic_c = (unsigned)((0x100000000ULL + (unsigned)cin8 - 1) / (unsigned)cin8);
+  p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)d->kw - 1) / (unsigned)d->kw);
+  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * cin8 * 2);
+  p.w_bytes = (unsigned)((size_t)d->n_pad16 * kp * 2);
+  dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
+  int rc = launch_fwd_epi<__bf16>(NT, grid, (hipStream_t)stream, p);
+  if (rc != EFM_OK) return rc;
+  return efm::check_launch("convb_mfm_fwd");
+}
+
+int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f32, uint16_t* dy, int batch, int h, int w, int c, int ways,
+                           int pool, void* stream) {
+  EFM_REQUIRE(route && dz && dy && batch > 0 && h > 0 && w > 0, "convb_mfm_pool_bwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "convb_mfm_pool_bwd: c=%d not divisible by ways=%d", c, ways);
+  const int cs = c / ways, cp = pad8(c), cw = cs + (cp - c), co = (ways == 3) ? 2 * cs : cs;
+  const long items = pool ? (long)batch * ((h + 1) / 2) * ((w + 1) / 2) : (long)batch * h * w;
+  dim3 grid((unsigned)efm::cdiv(items * cw, 256));
+  if (dz_f32)
+    hipLaunchKernelGGL((mfm_pool_bwd_k<float, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, route, (const float*)dz,
+                       reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cw, cp, efm_pad4(co));
+  else
+    hipLaunchKernelGGL((mfm_pool_bwd_k<__bf16, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, route, (const __bf16*)dz,
+                       reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cw, cp, pad8(co));
+  return efm::check_launch("convb_mfm_pool_bwd");
+}
+
+int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && dy && dw_packed, "convb_bwd_weight: null argument");
+  const WgradBPlan pl = plan_wgradb(d);
+  if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
+    efm::set_error("convb_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
+    return EFM_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  WgradBP p;
+  p.x = reinterpret_cast<const __bf16*>(x); p.dy = reinterpret_cast<const __bf16*>(dy); p.ws = (float*)workspace;
+  p.M = d->batch * d->hout * d->wout;
+  p.hin = d->hin; p.win = d->win; p.cin_p = pad8(d->cin);
+  p.hout = d->hout; p.wout = d->wout; p.cout_p = pad8(d->cout);
+  p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.n_pad16 = d->n_pad16; p.kb_pad = pl.kb_pad;
+  p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
+  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * p.cin_p * 2);
+  p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * p.cout_p * 2);
+  float* bpart = (float*)workspace + pl.slab_floats;
+  float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
+  p.bias_part = dbias ? bpart : nullptr;
+  p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
+  dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
+  int rc = (pl.KPW == 2) ? launch_wgradb_nt<2>(pl.NTW, grid, s, p) : launch_wgradb_nt<1>(pl.NTW, grid, s, p);
+  if (rc != EFM_OK) return rc;
+  rc = efm::check_launch("convb_wgrad");
+  if (rc != EFM_OK) return rc;
+  const long total = (long)d->n_pad16 * d->k_pad;
+  hipLaunchKernelGGL(slab_reduce_remap_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, s, (const float*)workspace, dw_packed, *d,
+                     pl.kb_pad, pl.splits, accumulate);
+  rc = efm::check_launch("convb_wgrad_reduce");
+  if (rc != EFM_OK || !dbias) return rc;
+  const long b4 = d->n_pad16 / 4;
+  const unsigned gx = (unsigned)efm::cdiv(b4, 64);
+  if (pl.bias_chunks > 32) {
+    const int groups = (pl.bias_chunks + 31) / 32;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, (const float*)bpart, bpart2, b4, b4, pl.bias_chunks, 32, b4, 0);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)bpart2, dbias, b4, b4, groups, groups, b4, accumulate);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)bpart, dbias, b4, b4, pl.bias_chunks, pl.bias_chunks, b4, accumulate);
+  }
+  return efm::check_launch("convb_bias_reduce");
 }
 
 }  // extern "C"

@@ -28,8 +28,8 @@ def _need_dev(*ts):
             continue
         if not t.is_cuda:
             raise _lib.EfmError("efm ops need device tensors (the HIP library is the only compute path)")
-        if t.dtype not in (torch.float32, torch.int32):
-            raise _lib.EfmError("efm ops take float32 / int32 tensors, got %s" % t.dtype)
+        if t.dtype not in (torch.float32, torch.int32, torch.bfloat16, torch.uint8):
+            raise _lib.EfmError("efm ops take float32 / bfloat16 / int32 / uint8 tensors, got %s" % t.dtype)
         if not t.is_contiguous():
             raise _lib.EfmError("efm ops need contiguous tensors")
 
@@ -352,3 +352,87 @@ def adam_update(w, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.0, 
     _need_dev(w, g, m, v)
     check(_lib.load().efm_adam_update(_p(w), _p(g), _p(m), _p(v), w.numel(), float(lr), float(beta1), float(beta2),
                                       float(eps), float(wd), float(rescale), int(step), _stream()), "efm_adam_update")
+
+
+# ------------------------------------------------------------------------------- bf16 tensor-core path
+def pad8(c):
+    return (c + 7) & ~7
+
+
+def pad32(c):
+    return (c + 31) & ~31
+
+
+def _bf(t):
+    assert t is None or t.dtype == torch.bfloat16, "bf16 path: expected a bfloat16 tensor"
+    return t
+
+
+def nchw_to_nhwc_bf16(x):
+    _need_dev(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, pad8(c)), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().efm_nchw_to_nhwc_bf16(_p(x), _p(out), b, c, h, w, _stream()), "efm_nchw_to_nhwc_bf16")
+    return out
+
+
+def convb_cast_weights(d, wp, wb=None, wdb=None, need_dgrad=True):
+    """fp32 packed master weight -> (bf16 forward weight, bf16 data-gradient weight or None)."""
+    _need_dev(wp, wb, wdb)
+    lib = _lib.load()
+    if wb is None:
+        wb = torch.empty(lib.efm_convb_weight_elems(ctypes.byref(d)), dtype=torch.bfloat16, device=wp.device)
+    if wdb is None and need_dgrad:
+        wdb = torch.empty(lib.efm_convb_dgrad_weight_elems(ctypes.byref(d)), dtype=torch.bfloat16, device=wp.device)
+    check(lib.efm_convb_cast_weights(ctypes.byref(d), _p(wp), _p(wb), _p(wdb if need_dgrad else None), _stream()), "efm_convb_cast_weights")
+    return wb, (wdb if need_dgrad else None)
+
+
+def convb_fwd(d, x, wb, bias=None, residual=None):
+    _need_dev(_bf(x), _bf(wb), bias, _bf(residual))
+    assert x.numel() == d.batch * d.hin * d.win * pad8(d.cin)
+    y = torch.empty((d.batch, d.hout, d.wout, pad8(d.cout)), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().efm_convb_fwd(ctypes.byref(d), _p(x), _p(wb), _p(bias), _p(residual), _p(y), _stream()), "efm_convb_fwd")
+    return y
+
+
+def convb_mfm_fwd(d, x, wb, bias, ways=3, order=_lib.MFM_ORDER_GROUP, pool=False, out_f32=False):
+    _need_dev(_bf(x), _bf(wb), bias)
+    assert x.numel() == d.batch * d.hin * d.win * pad8(d.cin)
+    co = mfm_out_channels(d.cout, ways)
+    cpo = pad4(co) if out_f32 else pad8(co)
+    ho, wo = (d.hout // 2, d.wout // 2) if pool else (d.hout, d.wout)
+    z = torch.empty((d.batch, ho, wo, cpo), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    route = torch.empty((d.batch, ho, wo, cpo), dtype=torch.uint8, device=x.device)
+    check(_lib.load().efm_convb_mfm_fwd(ctypes.byref(d), _p(x), _p(wb), _p(bias), _p(z), _p(route), ways, order, int(bool(pool)),
+                                        int(bool(out_f32)), _stream()), "efm_convb_mfm_fwd")
+    return z, route
+
+
+def convb_bwd_data(d, dy, wdb, add=None):
+    _need_dev(_bf(dy), _bf(wdb), _bf(add))
+    assert dy.numel() == d.batch * d.hout * d.wout * pad8(d.cout)
+    dx = torch.empty((d.batch, d.hin, d.win, pad8(d.cin)), dtype=torch.bfloat16, device=dy.device)
+    check(_lib.load().efm_convb_bwd_data(ctypes.byref(d), _p(dy), _p(wdb), _p(add), _p(dx), _stream()), "efm_convb_bwd_data")
+    return dx
+
+
+def convb_mfm_pool_bwd(d, route, dz, ways=3, pool=False):
+    _need_dev(dz, route)
+    dy = torch.empty((d.batch, d.hout, d.wout, pad8(d.cout)), dtype=torch.bfloat16, device=dz.device)
+    check(_lib.load().efm_convb_mfm_pool_bwd(_p(route), _p(dz), int(dz.dtype == torch.float32), _p(dy), d.batch, d.hout, d.wout, d.cout,
+                                             ways, int(bool(pool)), _stream()), "efm_convb_mfm_pool_bwd")
+    return dy
+
+
+def convb_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=False):
+    _need_dev(_bf(x), _bf(dy), dw, dbias)
+    if dw is None:
+        dw = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((d.n_pad16,), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = workspace(lib.efm_convb_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+    check(lib.efm_convb_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), int(bool(accumulate)), _p(ws),
+                                   ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_convb_bwd_weight")
+    return dw, (dbias if want_bias else None)

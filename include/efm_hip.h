@@ -124,6 +124,33 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
                         float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bf16 tensor-core path (BASELINE configs[2]: "bf16 — MFMA conv path").  Same operators, different storage:
+ *   activations  bf16 NHWC, channel stride pad8(c), pads zero;        (uint16_t* here = raw bf16 bits)
+ *   weights      bf16 packed wb[n][k], k = tap*pad8(cin) + ci, pad16(cout) rows of pad32(taps*pad8(cin)) elements,
+ *                cast every step from the fp32 master weights (which stay in the fp32 packed layout, as do all gradients);
+ *   arithmetic   v_mfma_f32_16x16x32_bf16, fp32 accumulate; the fused epilogue (bias, MFM, pool) runs on the fp32 accumulators.
+ * The weight gradient contracts over pixels: its operands are read from the [pixel][channel] LDS image with
+ * ds_read_b64_tr_b16 (hardware transpose).
+ * ------------------------------------------------------------------------------------ */
+size_t efm_convb_weight_elems(const efm_conv_desc* d);
+size_t efm_convb_dgrad_weight_elems(const efm_conv_desc* d);
+size_t efm_convb_wgrad_workspace_bytes(const efm_conv_desc* d);
+int efm_nchw_to_nhwc_bf16(const float* x_nchw, uint16_t* y_nhwc_bf16, int batch, int c, int h, int w, void* stream);
+/* fp32 packed master weight -> bf16 forward weight and (wdb != NULL) bf16 data-gradient weight */
+int efm_convb_cast_weights(const efm_conv_desc* d, const float* w_packed, uint16_t* wb, uint16_t* wdb, void* stream);
+int efm_convb_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, const uint16_t* residual,
+                  uint16_t* y, void* stream);
+/* z is bf16 (channel stride pad8) or, with out_f32 != 0, float (stride pad4): the layer that feeds the fp32 head */
+int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, void* z, unsigned char* route,
+                      int ways, int order, int pool, int out_f32, void* stream);
+int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_t* wdb, const uint16_t* add, uint16_t* dx, void* stream);
+int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f32, uint16_t* dy, int batch, int h, int w, int c, int ways,
+                           int pool, void* stream);
+/* dw_packed / dbias are FLOAT, in the fp32 packed layout of efm_conv_bwd_weight */
+int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).
  * ------------------------------------------------------------------------------------ */
 int efm_nchw_to_nhwc(const float* x_nchw, float* y_nhwc, int batch, int c, int h, int w, void* stream);
