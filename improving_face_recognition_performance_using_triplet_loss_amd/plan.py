@@ -46,9 +46,14 @@ class Step:
 
 
 class Plan:
-    def __init__(self, outputs, input_shape, device="cuda", fuse=None):
+    def __init__(self, outputs, input_shape, device="cuda", fuse=None, dtype="f32"):
         """fuse: fold `conv -> MFM [-> pool]` chains into the convolution's epilogue (default on; EFM_FUSE=0 or
-        fuse=False keeps one kernel per graph node — the form the oracle-routing parity test uses)."""
+        fuse=False keeps one kernel per graph node — the form the oracle-routing parity test uses).
+        dtype: "f32" (exact fp32 MFMA) or "bf16" (BASELINE configs[2]: bf16 activations / operands, fp32 accumulate, fp32
+        master weights and gradients; supported for networks whose every MFM / pooling is fused into a convolution)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         self.device = torch.device(device)
         self.batch = int(input_shape[0])
         self.input_shape = tuple(int(v) for v in input_shape)
@@ -59,6 +64,8 @@ class Plan:
         self.fused = 0
         if self.fuse:
             self._fuse()
+        if self.dtype == "bf16":
+            self._check_bf16()
         self._acts = None
         self._views = {}
         self._wd_scratch = None
@@ -201,6 +208,31 @@ class Plan:
         for k, st in enumerate(self.steps):
             st.index = k
 
+    def _check_bf16(self):
+        users = collections.defaultdict(list)
+        for st in self.steps:
+            for i in st.inputs:
+                users[i.index].append(st)
+        outs = {st.index for st in self.outputs}
+        for st in self.steps:
+            if st.op in ("mfm", "pool"):
+                raise NotImplementedError("bf16 plan: stand-alone %s '%s' (only MFM / pooling fused into a convolution)" % (st.op, st.node.name))
+            if st.op == "conv":
+                feeds_f32 = st.index in outs or any(u.op == "l2norm" for u in users[st.index])
+                if feeds_f32 and st.epi is None:
+                    raise NotImplementedError("bf16 plan: a plain convolution may not feed the fp32 head")
+                if st.inputs[0].op == "l2norm":
+                    raise NotImplementedError("bf16 plan: convolution on the fp32 head output")
+                st.out_f32 = feeds_f32
+                st.wb = st.wdb = None
+
+    def _cast_weights(self, v):
+        """bf16 copies of every weight (forward + data-gradient layouts) from the fp32 master buffer: once per step."""
+        for st in self.steps:
+            if st.op == "conv":
+                need_d = st.inputs[0].needs_grad
+                st.wb, st.wdb = ops.convb_cast_weights(st.desc, v[st.pname + "_weight"], st.wb, st.wdb, need_dgrad=need_d)
+
     # --------------------------------------------------------------------------- parameters
     def new_flat(self):
         return torch.zeros(self.num_flat, dtype=torch.float32, device=self.device)
@@ -273,9 +305,21 @@ class Plan:
         v = self.views(flat)
         acts = {}
         aux = {}
+        bf = self.dtype == "bf16"
+        if bf:
+            self._cast_weights(v)
         for st in self.steps:
             if st.op == "input":
-                acts[st.index] = ops.nchw_to_nhwc(x.contiguous())
+                acts[st.index] = ops.nchw_to_nhwc_bf16(x.contiguous()) if bf else ops.nchw_to_nhwc(x.contiguous())
+            elif st.op == "conv" and bf:
+                bias = None if st.no_bias else v[st.pname + "_bias"]
+                src = acts[st.inputs[0].index]
+                if st.epi is not None:
+                    acts[st.index], aux[st.index] = ops.convb_mfm_fwd(st.desc, src, st.wb, bias, st.epi["ways"], st.epi["order"],
+                                                                      st.epi["pool"], out_f32=st.out_f32)
+                else:
+                    res = acts[st.residual.index] if st.residual is not None else None
+                    acts[st.index] = ops.convb_fwd(st.desc, src, st.wb, bias, res)
             elif st.op == "conv":
                 w = v[st.pname + "_weight"]
                 bias = None if st.no_bias else v[st.pname + "_bias"]
@@ -340,26 +384,31 @@ class Plan:
             if st.op == "conv":
                 d = st.desc
                 src = st.inputs[0]
+                bf = self.dtype == "bf16"
                 if st.epi is not None:  # gradient of the fused MFM (+ pool) epilogue -> full conv-output gradient
-                    dy = ops.mfm_pool_bwd(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
+                    dy = (ops.convb_mfm_pool_bwd if bf else ops.mfm_pool_bwd)(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
+                wgrad = ops.convb_bwd_weight if bf else ops.conv_bwd_weight
                 wname = st.pname + "_weight"
                 acc = wname in written
                 if side is not None:
                     side.wait_stream(main)
                     dy.record_stream(side)
                     with torch.cuda.stream(side):
-                        ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
-                                            want_bias=not st.no_bias, accumulate=acc)
+                        wgrad(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
+                              want_bias=not st.no_bias, accumulate=acc)
                 else:
-                    ops.conv_bwd_weight(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
-                                        want_bias=not st.no_bias, accumulate=acc)
+                    wgrad(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
+                          want_bias=not st.no_bias, accumulate=acc)
                 written.add(wname)
                 if st.residual is not None:
                     r = st.residual.index
                     if r in gr:
                         raise NotImplementedError("two gradient contributions to a residual source before its own backward")
                     gr[r] = dy  # identity path: alias, consumed (read-only) by the source's other consumer
-                if src.needs_grad or (src.op == "input" and need_input_grad):
+                if bf and src.needs_grad:
+                    prev = gr.pop(src.index, None)
+                    gr[src.index] = ops.convb_bwd_data(d, dy, st.wdb, add=prev)
+                elif src.needs_grad or (src.op == "input" and need_input_grad):
                     wd = self._wd_scratch[: d.dn_pad16 * d.dk_pad]
                     ops.conv_make_dgrad_weights(d, v[wname], out=wd)
                     prev = gr.pop(src.index, None)

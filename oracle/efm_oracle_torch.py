@@ -86,9 +86,10 @@ def lightcnn9_forward(p, x):
     return mfm2(F.linear(cur.flatten(1), p["fc1_weight"], p["fc1_bias"]))
 
 
-def mining_step(forward, p, x, labels, pos, margin):
+def mining_step(forward, p, x, labels, pos, margin, backward=True):
     """Semi-hard step on any feature network: emb = rownorm(forward), cosine matrix, TF-addons semi-hard rule, indexed
-    triplet loss with detached negatives; returns (loss, emb, neg); gradients land in .grad of `p`."""
+    triplet loss with detached negatives; returns (loss, emb, neg); gradients land in .grad of `p`.  backward=False returns
+    the attached (loss, emb) instead so that a test can push its own upstream gradient through emb."""
     from oracle import efm_oracle as O
     feat = forward(p, x)
     emb = feat / feat.norm(dim=1, keepdim=True)
@@ -99,5 +100,78 @@ def mining_step(forward, p, x, labels, pos, margin):
     ok = torch.as_tensor(neg >= 0)
     n = emb[torch.as_tensor(np.where(neg >= 0, neg, 0))].detach()
     loss = torch.where(ok, triplet_loss(emb, emb[torch.as_tensor(pos.astype(np.int64))], n, margin), torch.zeros((), dtype=emb.dtype))
+    if not backward:
+        return loss, emb, neg
     loss.sum().backward()
     return loss.detach(), emb.detach(), neg
+
+
+# ---- emulation of the bf16 tensor-core path (BASELINE configs[2]): what is rounded to bf16 and where ----------------------
+class _RoundBoth(torch.autograd.Function):
+    """A tensor STORED in bf16: the value is rounded going forward, its gradient is rounded coming back."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 copy of an fp32 master weight: rounded going forward, full-precision gradient."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """fp32 accumulator consumed by the fused epilogue: untouched going forward, its gradient (dy) is stored in bf16."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+def lightcnn9_forward_bf16(p, x, forced=None, outs=None):
+    """LightCNN-9 as the bf16 plan computes it: bf16 activations and weights as conv operands, fp32 accumulate + bias + MFM2 + pool,
+    result stored in bf16 — except the last layer, which feeds the fp32 head.
+
+    A network of rounding steps is chaotic: an accumulator that differs in the last fp32 bit lands on the other side of a bf16
+    rounding boundary now and then, the next layer spreads that 2^-8 step over all its outputs, and after four layers device and
+    emulation agree only to the bf16 noise itself (3e-3), which in turn flips arg-max routes in backward (5 % gradient noise).
+    `forced` (the device's own stored activation of every layer, NCHW) removes the chaos without removing the check: each layer
+    then starts from the device's input values (gradients still flow through the emulation's chain), its own output — appended
+    to `outs` before the substitution — must equal the device's up to isolated one-ulp roundings, and the backward of the whole
+    chain is compared with routes that agree."""
+    k = 0
+
+    def store(z):
+        nonlocal k
+        cur = _RoundBoth.apply(z)
+        if outs is not None:
+            outs.append(cur.detach())
+        if forced is not None:
+            cur = cur + (forced[k] - cur).detach()
+        k += 1
+        return cur
+
+    cur = _RoundBoth.apply(x)
+    for layer, num_r, num, ksz, pad, pool in LIGHTCNN9_PLAN:
+        if num_r:
+            y = F.conv2d(cur, _RoundFwd.apply(p["conv%s_r_weight" % layer]), p["conv%s_r_bias" % layer])
+            cur = store(mfm2(_RoundBwd.apply(y)))
+        y = F.conv2d(cur, _RoundFwd.apply(p["conv%s_weight" % layer]), p["conv%s_bias" % layer], padding=pad)
+        z = mfm2(_RoundBwd.apply(y))
+        if pool:
+            z = F.max_pool2d(z, 2, 2)
+        cur = store(z)
+    y = F.linear(cur.flatten(1), _RoundFwd.apply(p["fc1_weight"]), p["fc1_bias"])
+    return mfm2(_RoundBwd.apply(y))
