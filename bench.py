@@ -19,6 +19,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_STEP = 15256522908  # SURVEY.md §8d / BASELINE.md §2: 3*fwd - dgrad(conv1), EFM-29 @112, unpadded
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense v_mfma_f32_16x16x32_bf16: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
@@ -39,6 +40,8 @@ def parse():
     ap.add_argument("--workload", choices=["efm", "lightcnn9"], default="efm",
                     help="efm = BASELINE configs[1] (default, the headline); lightcnn9 = configs[2] geometry in fp32 with in-batch "
                          "semi-hard mining (every image an anchor) — a secondary line, not the headline metric")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 (lightcnn9 only) = BASELINE configs[2]: bf16 operands / activations, fp32 accumulate + master weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
@@ -148,12 +151,14 @@ def main():
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
 
     flop_per_image = FLOP_PER_IMAGE_STEP
+    if args.dtype == "bf16" and args.workload != "lightcnn9":
+        raise SystemExit("--dtype bf16 is implemented for --workload lightcnn9 (BASELINE configs[2])")
     if args.workload == "lightcnn9":
         from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
         from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
         flop_per_image = 4667572224  # 3*fwd - dgrad(conv1), LightCNN-9 @112
         tr = MiningTripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
-                                  outputs=efm_symbol.lightcnn9_embedding_net())
+                                  outputs=efm_symbol.lightcnn9_embedding_net(), dtype=args.dtype)
         ids = (torch.arange(args.batch) // 4) + rank * (args.batch // 4)  # P = B/4 identities x K = 4 images
         tr.set_labels(ids)
         batches = [(synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device), None) for s in range(2)]
@@ -205,9 +210,14 @@ def main():
             "loss": round(loss_mean, 6),
         }
         if args.workload == "lightcnn9":
-            out["metric"] = "triplets/sec LightCNN-9 256-d 112x112, in-batch semi-hard mining, fp32 (secondary; BASELINE configs[2] asks bf16)"
-            out["config"] = {"workload": "LightCNN-9 (MFM2), %d images/GPU, every image an anchor, semi-hard negatives mined on device" % args.batch,
+            out["metric"] = "triplets/sec LightCNN-9 256-d 112x112, in-batch semi-hard mining, %s (secondary: BASELINE configs[2])" % args.dtype
+            out["dtype"] = args.dtype
+            out["config"] = {"workload": "BASELINE configs[2]: LightCNN-9 (MFM2), %d images/GPU, every image an anchor, semi-hard negatives "
+                                         "mined on device, %s" % (args.batch, "bf16 operands + fp32 accumulate / master weights"
+                                                                  if args.dtype == "bf16" else "fp32"),
                              "images_per_gpu": args.batch, "parallelism": "dp%d" % world}
+            peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+            out["step_mfma_roofline_frac"] = round(images / world * flop_per_image / (peak * 1e12), 4)
         else:
             out["roofline"] = dominant_kernel_roofline(tr, torch)
         if world == 1 and not args.no_cpu_baseline and args.workload == "efm":

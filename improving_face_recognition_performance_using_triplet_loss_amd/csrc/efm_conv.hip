@@ -1109,7 +1109,7 @@ int launch_wgradb_nt(int NTW, dim3 grid, hipStream_t s, const WgradBP& p) {
 
 struct WgradBPlan {
   int KPW, NTW, kblocks, nblocks, splits, m_per_split, bias_chunks, kb_pad;
-  size_t slab_floats, ws_floats;
+  size_t slab_floats, lvl2_floats, ws_floats;
 };
 
 WgradBPlan plan_wgradb(const efm_conv_desc* d) {
@@ -1123,8 +1123,8 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
   pl.NTW = round_nt((ntiles + nb - 1) / nb);
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
-  int splits = (env_int("EFM_WGRAD_BLOCKS", 2560) + base - 1) / base;
-  const int max_splits = std::min(32, (M + 1023) / 1024);  // the remap reduction walks the slabs serially: keep them few
+  int splits = (env_int("EFM_WGRADB_BLOCKS", 1024) + base - 1) / base;
+  const int max_splits = std::min(1024, (M + 1023) / 1024);  // >= 32 contraction steps per block; > 32 slabs reduce in two levels
   splits = std::max(1, std::min(splits, max_splits));
   int mps = (M + splits - 1) / splits;
   mps = (mps + 31) & ~31;
@@ -1132,7 +1132,8 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
   pl.splits = (M + mps - 1) / mps;
   pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
   pl.slab_floats = (size_t)pl.splits * d->n_pad16 * pl.kb_pad;
-  pl.ws_floats = pl.slab_floats + (size_t)(pl.bias_chunks + (pl.bias_chunks + 31) / 32) * d->n_pad16;
+  pl.lvl2_floats = pl.splits > 32 ? (size_t)32 * d->n_pad16 * pl.kb_pad : 0;
+  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.bias_chunks + (pl.bias_chunks + 31) / 32) * d->n_pad16;
   return pl;
 }
 
@@ -1426,7 +1427,8 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
   p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * p.cin_p * 2);
   p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * p.cout_p * 2);
-  float* bpart = (float*)workspace + pl.slab_floats;
+  float* lvl2 = (float*)workspace + pl.slab_floats;
+  float* bpart = lvl2 + pl.lvl2_floats;
   float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
   p.bias_part = dbias ? bpart : nullptr;
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
@@ -1436,8 +1438,17 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
   rc = efm::check_launch("convb_wgrad");
   if (rc != EFM_OK) return rc;
   const long total = (long)d->n_pad16 * d->k_pad;
-  hipLaunchKernelGGL(slab_reduce_remap_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, s, (const float*)workspace, dw_packed, *d,
-                     pl.kb_pad, pl.splits, accumulate);
+  const float* slabs = (const float*)workspace;
+  int nslabs = pl.splits;
+  if (pl.splits > 32) {  // level 1: groups of slabs -> at most 32 partial slabs
+    const long n4 = (long)d->n_pad16 * pl.kb_pad / 4;
+    const int per_group = (pl.splits + 31) / 32;
+    nslabs = (pl.splits + per_group - 1) / per_group;
+    hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(n4, 64), nslabs), dim3(256), 0, s, slabs, lvl2, n4, n4, pl.splits, per_group, n4, 0);
+    slabs = lvl2;
+  }
+  hipLaunchKernelGGL(slab_reduce_remap_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, s, slabs, dw_packed, *d,
+                     pl.kb_pad, nslabs, accumulate);
   rc = efm::check_launch("convb_wgrad_reduce");
   if (rc != EFM_OK || !dbias) return rc;
   const long b4 = d->n_pad16 / 4;
