@@ -372,10 +372,13 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   }
 }
 
+#ifndef EFM_FWD_OCC
+#define EFM_FWD_OCC 2
+#endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 template <typename T, int MT, int NT, bool DMA, int EPI>
-__global__ void __launch_bounds__(256, 2) conv_fwd_k(const ConvP p) {
+__global__ void __launch_bounds__(256, EFM_FWD_OCC) conv_fwd_k(const ConvP p) {
   // K-loop double buffer, re-used by the fused epilogue as 4 per-wave transposition regions of R rows x (BN + 4)
   __shared__ __attribute__((aligned(16))) float smem[cmax(2 * (MT * 64 + NT * 16) * 16,
                                                             EPI ? 4 * ((NT <= 8) ? 16 : 8) * (NT * 16 + 4) : 0)];
@@ -722,12 +725,17 @@ int env_int(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
+// Rows per block = 64 * MT.  A bf16 MFMA is 8x shorter than the fp32 one on the same fragment bytes, so the bf16 kernels need
+// the B fragments re-used over several row tiles (MT = 2, 4) to get off the LDS-bandwidth bound: MFMA cycles / LDS cycles per
+// K step = MT*NT / (2*(MT + NT)).  The accumulators (4*MT*NT registers) cap the product.
+constexpr int mt_fit(int mt, int nt) { return (mt * nt <= 44) ? mt : ((2 * nt <= 44) ? 2 : 1); }
+
 template <typename T, int MT, bool DMA>
 int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<T, MT, N, DMA, 0>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<T, mt_fit(MT, N), N, DMA, 0>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7) EFM_CASE(8) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13)
 #undef EFM_CASE
@@ -736,13 +744,13 @@ int launch_fwd_nt(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   return EFM_E_INVALID;
 }
 
-// fused-epilogue variants: one channel block holds every slice of a channel, 64-row tiles
-template <typename T>
+// fused-epilogue variants: one channel block holds every slice of a channel
+template <typename T, int MT>
 int launch_fwd_epi(int NT, dim3 grid, hipStream_t s, const ConvP& p) {
   switch (NT) {
 #define EFM_CASE(N)                                          \
   case N:                                                    \
-    hipLaunchKernelGGL((conv_fwd_k<T, 1, N, true, 1>), grid, dim3(256), 0, s, p); \
+    hipLaunchKernelGGL((conv_fwd_k<T, mt_fit(MT, N), N, true, 1>), grid, dim3(256), 0, s, p); \
     return EFM_OK;
     EFM_CASE(3) EFM_CASE(5) EFM_CASE(7) EFM_CASE(9) EFM_CASE(11) EFM_CASE(13) EFM_CASE(17) EFM_CASE(25)
 #undef EFM_CASE
@@ -763,6 +771,16 @@ int round_nt(int nt) {
   for (int v : ok)
     if (v >= nt) return v;
   return 13;
+}
+
+// bf16: the largest row tile that still leaves >= 3 blocks per CU.  256-row tiles (MT = 4) are built and selectable through the
+// tune field, but measured equal or slightly slower than 128 rows on LightCNN-9 (the small-N layers are bound by the 9x im2col
+// re-fetch of the A operand through L2 -> LDS, not by B-fragment re-use), so the default stops at 2.
+int pick_mt_bf16(long M, int nblocks) {
+  const int want = env_int("EFM_CONVB_MIN_BLOCKS", 768);
+  if (env_int("EFM_CONVB_MT_MAX", 2) >= 4 && efm::cdiv(M, 256) * nblocks >= want) return 4;
+  if (efm::cdiv(M, 128) * nblocks >= want) return 2;
+  return 1;
 }
 
 // Generic forward-type launch: y[m][n] = sum_k A(x)[m][k] w[n][k] + bias[n] + res[m][n]
@@ -788,8 +806,11 @@ int run_fwd(const void* x, const void* w, const float* bias, const void* res, vo
   // tiles for NT >= 7; narrow tiles (NT <= 6) amortise the pixel-tile staging better with 128 rows.
   int MT = (NT >= 7) ? 1 : 2;
   if ((long)efm::cdiv(p.M, 128) * p.nblocks < 1024) MT = 1;
-  if ((tune & 15) == 1 || (tune & 15) == 2) MT = tune & 15;
+  if (sizeof(T) == 2) MT = pick_mt_bf16(p.M, p.nblocks);
+  if ((tune & 15) == 1 || (tune & 15) == 2 || ((tune & 15) == 4 && sizeof(T) == 2)) MT = tune & 15;
   MT = env_int("EFM_CONV_MT", MT);
+  if (sizeof(T) == 4 && MT > 2) MT = 2;
+  MT = mt_fit(MT, NT);
   const int BM = 64 * MT;
   const long mblocks = efm::cdiv(p.M, BM);
   dim3 grid((unsigned)(mblocks * p.nblocks));
@@ -799,7 +820,9 @@ int run_fwd(const void* x, const void* w, const float* bias, const void* res, vo
   p.w_bytes = (unsigned)((size_t)n_pad16 * k_pad * sizeof(T));
   const bool dma = sizeof(T) == 2 || env_int("EFM_CONV_DMA", 1) != 0;
   int rc;
-  if (dma)
+  if (dma && sizeof(T) == 2 && MT == 4)
+    rc = launch_fwd_nt<__bf16, 4, true>(NT, grid, s, p);
+  else if (dma)
     rc = (MT == 2) ? launch_fwd_nt<T, 2, true>(NT, grid, s, p) : launch_fwd_nt<T, 1, true>(NT, grid, s, p);
   else
     rc = (MT == 2) ? launch_fwd_nt<float, 2, false>(NT, grid, s, p) : launch_fwd_nt<float, 1, false>(NT, grid, s, p);
@@ -1241,7 +1264,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
   dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
-  int rc = launch_fwd_epi<float>(NT, grid, (hipStream_t)stream, p);
+  int rc = launch_fwd_epi<float, 1>(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_mfm_fwd");
 }
@@ -1386,8 +1409,13 @@ int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t*
   p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)d->kw - 1) / (unsigned)d->kw);
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * cin8 * 2);
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * kp * 2);
-  dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
-  int rc = launch_fwd_epi<__bf16>(NT, grid, (hipStream_t)stream, p);
+  int MT = pick_mt_bf16(p.M, nsplit);
+  if ((d->tune_fwd & 15) == 1 || (d->tune_fwd & 15) == 2 || (d->tune_fwd & 15) == 4) MT = d->tune_fwd & 15;
+  MT = mt_fit(env_int("EFM_CONV_MT", MT), NT);
+  dim3 grid((unsigned)(efm::cdiv(p.M, 64 * MT) * nsplit));
+  int rc = (MT == 4)   ? launch_fwd_epi<__bf16, 4>(NT, grid, (hipStream_t)stream, p)
+           : (MT == 2) ? launch_fwd_epi<__bf16, 2>(NT, grid, (hipStream_t)stream, p)
+                       : launch_fwd_epi<__bf16, 1>(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("convb_mfm_fwd");
 }

@@ -34,8 +34,12 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--net", choices=["efm", "lightcnn9"], default="efm")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     a = ap.parse_args()
-    plan = Plan(efm_symbol.embedding_net(), (a.batch, 3, a.image, a.image), fuse=True)
+    net = efm_symbol.embedding_net() if a.net == "efm" else efm_symbol.lightcnn9_embedding_net()
+    plan = Plan(net, (a.batch, 3, a.image, a.image), fuse=True, dtype=a.dtype)
+    bf = a.dtype == "bf16"
     want = set(a.layers.split(",")) if a.layers else None
     what = a.what.split(",")
     tot = {k: 0.0 for k in what}
@@ -59,13 +63,30 @@ def main():
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty_like(b)
+        if bf:
+            c8 = lambda c: (c + 7) & ~7  # noqa: E731
+            xb = torch.zeros((d.batch, d.hin, d.win, c8(d.cin)), device="cuda", dtype=torch.bfloat16)
+            xb[..., :d.cin] = x[..., :d.cin].bfloat16()
+            dyb = torch.zeros((d.batch, d.hout, d.wout, c8(d.cout)), device="cuda", dtype=torch.bfloat16)
+            dyb[..., :d.cout] = dy[..., :d.cout].bfloat16()
+            wb, wdb = ops.convb_cast_weights(d, w)
         flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
         line = "%-14s %3dx%-3d %3d->%-3d k%d M=%-7d" % (st.pname, d.hin, d.win, d.cin, d.cout, d.kh, d.batch * d.hout * d.wout)
         for k in what:
             if k == "dgrad" and not st.inputs[0].needs_grad:
                 line += "  dgrad   --           "
                 continue
-            if k == "fwd":
+            if bf:
+                if k == "fwd":
+                    ms = timeit(lambda: ops.convb_fwd(d, xb, wb, b), a.iters)
+                    if st.epi is not None:
+                        ms2 = timeit(lambda: ops.convb_mfm_fwd(d, xb, wb, b, st.epi["ways"], st.epi["order"], st.epi["pool"]), a.iters)
+                        line += "  fused %7.3f ms %6.1f TF |" % (ms2, flops / ms2 / 1e9)
+                elif k == "dgrad":
+                    ms = timeit(lambda: ops.convb_bwd_data(d, dyb, wdb), a.iters)
+                else:
+                    ms = timeit(lambda: ops.convb_bwd_weight(d, xb, dyb, dw=dw, dbias=db), a.iters)
+            elif k == "fwd":
                 ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
                 if st.epi is not None:
                     ms2 = timeit(lambda: ops.conv_mfm_fwd(d, x, w, b, st.epi["ways"], st.epi["order"], st.epi["pool"]), a.iters)
