@@ -203,3 +203,35 @@ def test_fused_plan_is_bitwise_equal_to_unfused():
         tr.backward()
         res.append((loss, tr.last["emb"].clone(), tr.grad.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def test_config1_64_faces_vs_committed_golden():
+    """BASELINE configs[0]: EFM-29 on 64 synthetic 112x112x3 faces, embeddings + triplet loss + the cosine rows train_efm.py logs,
+    against tests/golden/config1_efm112.npz (torch-CPU fp64 restatement; no oracle call at test time)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_config1_golden as M
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config1_efm112.npz"))
+    params, w_head, x, neg = M.inputs()
+    tr = TripletTrainer(M.BATCH, image=M.IMAGE)
+    allp = dict(params)
+    allp["head_weight"] = w_head
+    tr.plan.load_params(tr.flat, allp)
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), torch.as_tensor(neg).cuda())
+    emb = tr.last["emb"]
+    e_emb = rel_err(emb.cpu().numpy(), z["emb"])
+    assert e_emb < TOL, e_emb
+    assert rel_err(loss.cpu().numpy(), z["loss"]) < TOL
+    feat = tr.last["feat"][:, :342].double().cpu().numpy()
+    assert np.abs(feat.sum(1) / z["feat_sum"] - 1).max() < TOL
+    assert np.abs(np.abs(feat).sum(1) / z["feat_abs"] - 1).max() < TOL
+    h = M.BATCH // 2
+    s_ap, s_an = ops.cosine_pairs(emb[:h], emb[h:], emb[:h][torch.as_tensor(neg).long().cuda()].contiguous())
+    assert rel_err(torch.stack([s_ap, s_an], 1).cpu().numpy(), z["cosines"]) < TOL
+    # the part of the loss that is not the margin (d_ap - d_an, ~1e-3 of it on an untrained net) still agrees to 1e-3 of its own scale
+    dl, dr = loss.cpu().numpy() - 0.2, z["loss"] - 0.2
+    print("config-1 golden: emb %.2e, (loss - margin) %.2e of %.2e" % (e_emb, np.abs(dl - dr).max(), np.abs(dr).max()))
+    assert np.abs(dl - dr).max() < 1e-3 * np.abs(dr).max() + 1e-7

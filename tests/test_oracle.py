@@ -237,3 +237,24 @@ def test_factor_scheduler_module_matches_oracle():
     s.base_lr = 2.4e-4
     for n in (1, 6, 7, 12, 13, 100, 1000):
         assert math.isclose(s(n), O.factor_scheduler(2.4e-4, n, 6, 0.88, 5e-15), rel_tol=1e-12)
+
+
+def test_oracle_reproduces_config1_golden_rows():
+    """BASELINE configs[0] fixture (tests/golden/config1_efm112.npz): the torch restatement regenerates rows 0, 31 and 63 (every
+    embedding row depends on its own image only) — pins the oracle against drift at the BASELINE geometry; the fp32 run of the
+    same restatement shows the headroom under the 1e-3 tolerance."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_config1_golden as M
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config1_efm112.npz"))
+    rows = [0, 31, 63]
+    params, w_head, x, neg = M.inputs(rows)
+    feat, emb = M.forward(params, w_head, x)
+    assert np.abs(emb - z["emb"][rows]).max() < 1e-6 * np.abs(z["emb"]).max()
+    assert np.abs(feat.sum(1) / z["feat_sum"][rows] - 1).max() < 1e-9
+    loss, cosines = M.loss_and_cosines(z["emb"].astype(np.float64), z["neg"])
+    assert np.abs(loss - z["loss"]).max() < 1e-6 and np.abs(cosines - z["cosines"]).max() < 1e-6
+    p32 = {k: v.astype(np.float32) for k, v in params.items()}
+    _, emb32 = M.forward(p32, w_head.astype(np.float32), x.astype(np.float32))
+    assert np.abs(emb32 - z["emb"][rows]).max() < 1e-4 * np.abs(z["emb"]).max()
