@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE: 256)")
     ap.add_argument("--image", type=int, default=112)
-    ap.add_argument("--workload", choices=["efm", "lightcnn9"], default="efm",
+    ap.add_argument("--workload", choices=["efm", "lightcnn9", "deepcnn"], default="efm",
                     help="efm = BASELINE configs[1] (default, the headline); lightcnn9 = configs[2] geometry in fp32 with in-batch "
                          "semi-hard mining (every image an anchor) — a secondary line, not the headline metric")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -151,14 +151,17 @@ def main():
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
 
     flop_per_image = FLOP_PER_IMAGE_STEP
-    if args.dtype == "bf16" and args.workload != "lightcnn9":
-        raise SystemExit("--dtype bf16 is implemented for --workload lightcnn9 (BASELINE configs[2])")
-    if args.workload == "lightcnn9":
+    if args.dtype == "bf16" and args.workload == "efm":
+        raise SystemExit("--dtype bf16 is implemented for --workload lightcnn9 / deepcnn (BASELINE configs[2], [4])")
+    if args.workload in ("lightcnn9", "deepcnn"):
         from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
         from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
-        flop_per_image = 4667572224  # 3*fwd - dgrad(conv1), LightCNN-9 @112
+        deep = args.workload == "deepcnn"
+        # 3*fwd - dgrad(conv1): LightCNN-9 @112 / the deeper CNN (fwd 5 199 839 232, conv1 dgrad 180 633 600)
+        flop_per_image = 3 * 5199839232 - 180633600 if deep else 4667572224
         tr = MiningTripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
-                                  outputs=efm_symbol.lightcnn9_embedding_net(), dtype=args.dtype)
+                                  outputs=efm_symbol.deepcnn_embedding_net() if deep else efm_symbol.lightcnn9_embedding_net(),
+                                  dtype=args.dtype)
         ids = (torch.arange(args.batch) // 4) + rank * (args.batch // 4)  # P = B/4 identities x K = 4 images
         tr.set_labels(ids)
         batches = [(synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device), None) for s in range(2)]
@@ -209,11 +212,12 @@ def main():
             "step_mfma_roofline_frac": round(images / world * flop_per_image / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "loss": round(loss_mean, 6),
         }
-        if args.workload == "lightcnn9":
-            out["metric"] = "triplets/sec LightCNN-9 256-d 112x112, in-batch semi-hard mining, %s (secondary: BASELINE configs[2])" % args.dtype
+        if args.workload in ("lightcnn9", "deepcnn"):
+            name, cfg = (("deeper CNN 512-d", 4) if args.workload == "deepcnn" else ("LightCNN-9 256-d", 2))
+            out["metric"] = "triplets/sec %s 112x112, in-batch semi-hard mining, %s (secondary: BASELINE configs[%d])" % (name, args.dtype, cfg)
             out["dtype"] = args.dtype
-            out["config"] = {"workload": "BASELINE configs[2]: LightCNN-9 (MFM2), %d images/GPU, every image an anchor, semi-hard negatives "
-                                         "mined on device, %s" % (args.batch, "bf16 operands + fp32 accumulate / master weights"
+            out["config"] = {"workload": "BASELINE configs[%d]: %s (MFM2), %d images/GPU, every image an anchor, semi-hard negatives "
+                                         "mined on device, %s" % (cfg, name, args.batch, "bf16 operands + fp32 accumulate / master weights"
                                                                   if args.dtype == "bf16" else "fp32"),
                              "images_per_gpu": args.batch, "parallelism": "dp%d" % world}
             peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS

@@ -101,3 +101,33 @@ def lightcnn9_embedding_net(normalize=True):
     feat = lightcnn9_feature(data)
     emb = G.L2Normalization(feat, name="l2norm") if normalize else feat
     return [emb, feat]
+
+
+# BASELINE configs[4]: "DeepFace-style deeper CNN, 512-d embedding" — named by the reference's README (README.md:9,17-19) without
+# any code; build-defined here as the LightCNN recipe carried deeper and wider (13 convolutions + fc, 2-way MFM after every
+# convolution, four 2x2 poolings).  Flat list of (name, output channels before MFM, kernel, pad, pool after).
+DEEPCNN_LAYERS = [
+    ("conv1", 96, 5, 2, True),
+    ("conv2_r", 96, 1, 0, False), ("conv2a", 192, 3, 1, False), ("conv2b", 192, 3, 1, True),
+    ("conv3_r", 192, 1, 0, False), ("conv3a", 384, 3, 1, False), ("conv3b", 384, 3, 1, True),
+    ("conv4_r", 384, 1, 0, False), ("conv4a", 512, 3, 1, False), ("conv4b", 512, 3, 1, False),
+    ("conv5_r", 512, 1, 0, False), ("conv5a", 512, 3, 1, False), ("conv5b", 512, 3, 1, True)]
+
+
+def mfm2_stack_feature(data, layers, fc_hidden):
+    """[conv -> MFM2 (-> pool)] per entry of `layers`, then fc -> MFM2: every convolution's MFM / pooling folds into its epilogue,
+    so the plan runs in fp32 or bf16."""
+    x = data
+    for name, num, k, pad, pool in layers:
+        x = G.MFM(G.Convolution(x, num, (k, k), name=name, pad=(pad, pad)), 2, G.ORDER_GROUP, name="mfm_" + name)
+        if pool:
+            x = G.Pooling(x, name="pool_" + name)
+    return G.MFM(G.FullyConnected(x, fc_hidden, name="fc1"), 2, G.ORDER_GROUP, name="mfm_fc1")
+
+
+def deepcnn_embedding_net(normalize=True):
+    """[512-d embedding (per-row L2 normalised), raw 512-d feature] of the build-defined deeper CNN (BASELINE configs[4])."""
+    data = G.Variable("data")
+    feat = mfm2_stack_feature(data, DEEPCNN_LAYERS, 1024)
+    emb = G.L2Normalization(feat, name="l2norm") if normalize else feat
+    return [emb, feat]

@@ -56,3 +56,16 @@ def negative_indices(labels, seed):
     if not bool(ok.any(dim=1).all()):
         raise RuntimeError("no negative found in 64 draws")
     return draws[torch.arange(h), first].to(torch.int32)
+
+
+def identity_faces(ids, channels, size, seed, noise=0.25, grid=7, device="cuda"):
+    """Synthetic 'faces' with identity structure (for runs that report a verification accuracy): each identity is a smooth
+    random pattern (a `grid` x `grid` random field, bilinearly enlarged, fixed by the identity id) and every image of it adds
+    its own U[-noise, noise) pixel noise; values stay in [0, 1].  ids: int tensor (B,); seed varies the per-image noise."""
+    import torch.nn.functional as F
+    ids = torch.as_tensor(ids, dtype=torch.int64).cpu()
+    cells = channels * grid * grid
+    base = torch.stack([uniform01(cells, 0x5EED0000 + int(i), device) for i in ids]).view(len(ids), channels, grid, grid)
+    faces = F.interpolate(base, size=(size, size), mode="bilinear", align_corners=False)
+    eps = (images(len(ids), channels, size, seed, device) * 2 - 1) * noise
+    return (faces * (1 - 2 * noise) + noise + eps).clamp_(0.0, 1.0).contiguous()

@@ -140,8 +140,39 @@ class _RoundBwd(torch.autograd.Function):
         return g.bfloat16().to(g.dtype)
 
 
-def lightcnn9_forward_bf16(p, x, forced=None, outs=None):
-    """LightCNN-9 as the bf16 plan computes it: bf16 activations and weights as conv operands, fp32 accumulate + bias + MFM2 + pool,
+def lightcnn9_layers():
+    """LIGHTCNN9_PLAN as the flat (name, kernel pad, pool) list the generic MFM2-stack functions take."""
+    out = []
+    for layer, num_r, num, k, pad, pool in LIGHTCNN9_PLAN:
+        if num_r:
+            out.append(("conv%s_r" % layer, 0, False))
+        out.append(("conv%s" % layer, pad, pool))
+    return out
+
+
+# BASELINE configs[4]'s build-defined deeper CNN (efm_symbol.DEEPCNN_LAYERS restated: name, pad, pool)
+DEEPCNN_LAYERS = [("conv1", 2, True), ("conv2_r", 0, False), ("conv2a", 1, False), ("conv2b", 1, True),
+                  ("conv3_r", 0, False), ("conv3a", 1, False), ("conv3b", 1, True),
+                  ("conv4_r", 0, False), ("conv4a", 1, False), ("conv4b", 1, False),
+                  ("conv5_r", 0, False), ("conv5a", 1, False), ("conv5b", 1, True)]
+
+
+def mfm2_stack_forward(p, x, layers):
+    """[conv -> MFM2 (-> 2x2 max pool)] per layer, then fc1 -> MFM2 (kernel sizes come from the weight shapes)."""
+    cur = x
+    for name, pad, pool in layers:
+        cur = mfm2(F.conv2d(cur, p[name + "_weight"], p[name + "_bias"], padding=pad))
+        if pool:
+            cur = F.max_pool2d(cur, 2, 2)
+    return mfm2(F.linear(cur.flatten(1), p["fc1_weight"], p["fc1_bias"]))
+
+
+def deepcnn_forward(p, x):
+    return mfm2_stack_forward(p, x, DEEPCNN_LAYERS)
+
+
+def mfm2_stack_forward_bf16(p, x, layers, forced=None, outs=None):
+    """An MFM2 stack (LightCNN-9, the deeper CNN) as the bf16 plan computes it: bf16 activations and weights as conv operands, fp32 accumulate + bias + MFM2 + pool,
     result stored in bf16 — except the last layer, which feeds the fp32 head.
 
     A network of rounding steps is chaotic: an accumulator that differs in the last fp32 bit lands on the other side of a bf16
@@ -164,14 +195,19 @@ def lightcnn9_forward_bf16(p, x, forced=None, outs=None):
         return cur
 
     cur = _RoundBoth.apply(x)
-    for layer, num_r, num, ksz, pad, pool in LIGHTCNN9_PLAN:
-        if num_r:
-            y = F.conv2d(cur, _RoundFwd.apply(p["conv%s_r_weight" % layer]), p["conv%s_r_bias" % layer])
-            cur = store(mfm2(_RoundBwd.apply(y)))
-        y = F.conv2d(cur, _RoundFwd.apply(p["conv%s_weight" % layer]), p["conv%s_bias" % layer], padding=pad)
+    for name, pad, pool in layers:
+        y = F.conv2d(cur, _RoundFwd.apply(p[name + "_weight"]), p[name + "_bias"], padding=pad)
         z = mfm2(_RoundBwd.apply(y))
         if pool:
             z = F.max_pool2d(z, 2, 2)
         cur = store(z)
     y = F.linear(cur.flatten(1), _RoundFwd.apply(p["fc1_weight"]), p["fc1_bias"])
     return mfm2(_RoundBwd.apply(y))
+
+
+def lightcnn9_forward_bf16(p, x, forced=None, outs=None):
+    return mfm2_stack_forward_bf16(p, x, lightcnn9_layers(), forced, outs)
+
+
+def deepcnn_forward_bf16(p, x, forced=None, outs=None):
+    return mfm2_stack_forward_bf16(p, x, DEEPCNN_LAYERS, forced, outs)

@@ -92,15 +92,19 @@ def test_convb_fused_epilogue(ways, pool, out_f32):
     assert rel_err(from_nhwc(dy, cout), bf(dy_ref)) < 1e-6
 
 
-def test_lightcnn9_bf16_step_vs_emulation():
-    """Whole LightCNN-9 mining step in bf16 against the torch-CPU emulation of the same rounding points (fp64 in between).
-    Free-running, device and emulation decorrelate to the bf16 noise level after a few layers (see the oracle's docstring), so
-    the tight comparison is teacher-forced: every emulated layer starts from the device's stored activation."""
+@pytest.mark.parametrize("net", ["lightcnn9", "deepcnn"])
+def test_mfm2_stack_bf16_step_vs_emulation(net):
+    """Whole mining step in bf16 — LightCNN-9 (BASELINE configs[2]) and the deeper 512-d CNN (configs[4]) — against the torch-CPU
+    emulation of the same rounding points (fp64 in between).  Free-running, device and emulation decorrelate to the bf16 noise
+    level after a few layers (see the oracle's docstring), so the tight comparison is teacher-forced: every emulated layer
+    starts from the device's stored activation."""
     from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
     from oracle import efm_oracle_torch as OT
     batch, image = 16, 32
-    tr = MiningTripletTrainer(batch, image=image, outputs=efm_symbol.lightcnn9_embedding_net(), seed=7, dtype="bf16")
+    outputs, fwd = ((efm_symbol.lightcnn9_embedding_net(), OT.lightcnn9_forward_bf16) if net == "lightcnn9"
+                    else (efm_symbol.deepcnn_embedding_net(), OT.deepcnn_forward_bf16))
+    tr = MiningTripletTrainer(batch, image=image, outputs=outputs, seed=7, dtype="bf16")
     labels = (np.arange(batch) // 4).astype(np.int32)
     tr.set_labels(labels)
     params = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.export_params(tr.flat).items()}
@@ -110,7 +114,7 @@ def test_lightcnn9_bf16_step_vs_emulation():
     # (1) free-running emulation: mined negatives, loss and embeddings at the bf16 noise level
     tp = {k: torch.tensor(v) for k, v in params.items()}
     with torch.no_grad():
-        loss_r, emb_r, neg_r = OT.mining_step(OT.lightcnn9_forward_bf16, tp, torch.tensor(x), labels, pos, 0.2, backward=False)
+        loss_r, emb_r, neg_r = OT.mining_step(fwd, tp, torch.tensor(x), labels, pos, 0.2, backward=False)
     neg = torch.as_tensor(neg_r.astype(np.int32)).cuda()
     loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg_idx=neg)
     emb_d = tr.last["emb"]
@@ -121,25 +125,25 @@ def test_lightcnn9_bf16_step_vs_emulation():
 
     # (2) teacher-forced: per-layer outputs equal up to isolated one-ulp roundings; feature vector to fp32 accumulation noise
     convs = [st for st in tr.plan.steps if st.op == "conv"]
-    dev = []
+    dev, chans = [], []
     for st in convs:
         t = tr.plan._acts[st.index]
         d = st.desc
-        c_out = t.shape[-1] if t.dim() == 2 else None
-        t = t.reshape(d.batch, t.shape[1] if t.dim() == 4 else 1, t.shape[2] if t.dim() == 4 else 1, -1)
-        dev.append(t)
+        dev.append(t.reshape(d.batch, t.shape[1] if t.dim() == 4 else 1, t.shape[2] if t.dim() == 4 else 1, -1))
+        chans.append(d.cout // 2)
+    nl = len(convs) - 1  # all but fc1 hand their stored activation to the next layer
     tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
-    chans = [48, 48, 96, 96, 192, 192, 128, 128, 128]
-    forced = [dev[i][..., :chans[i]].permute(0, 3, 1, 2).double().cpu() for i in range(9)]
+    forced = [dev[i][..., :chans[i]].permute(0, 3, 1, 2).double().cpu() for i in range(nl)]
     outs = []
-    feat = OT.lightcnn9_forward_bf16(tp, torch.tensor(x), forced=forced, outs=outs)
-    for i in range(9):
+    feat = fwd(tp, torch.tensor(x), forced=forced, outs=outs)
+    for i in range(nl):
         a, b = forced[i].numpy(), outs[i].numpy()
         assert a.shape == b.shape
         diff = np.abs(a - b)
-        assert (diff <= np.abs(b) * 2.0 ** -7 + 1e-30).all(), (i, diff.max())
+        # one bf16 ulp of the value, or — where a sum cancels to ~0 — the fp32 accumulation noise of its terms
+        assert (diff <= np.abs(b) * 2.0 ** -7 + 1e-6 * np.abs(b).max()).all(), (i, diff.max())
         assert (diff > 0).mean() < 5e-3, (i, (diff > 0).mean())
-    feat_d = dev[9].reshape(batch, -1)[:, :feat.shape[1]].double().cpu().numpy()
+    feat_d = dev[nl].reshape(batch, -1)[:, :feat.shape[1]].double().cpu().numpy()
     assert rel_err(feat_d, feat.detach().numpy()) < 1e-5
     emb_t = feat / feat.norm(dim=1, keepdim=True)
     assert rel_err(emb_d.cpu().numpy(), emb_t.detach().numpy()) < 1e-5
@@ -150,10 +154,15 @@ def test_lightcnn9_bf16_step_vs_emulation():
     tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
     g = tr.plan.export_params(tr.grad)
     errs = {k: rel_err(g[k].cpu().numpy().reshape(tp[k].shape), tp[k].grad.numpy()) for k in tp}
-    print("bf16 LightCNN-9: free-running emb %.2e; teacher-forced gradient worst %.2e" % (e_free, max(errs.values())))
-    # 1.2e-5 at fc1 growing to 2.5e-3 at conv1: one-ulp differences of the bf16-stored gradients accumulate linearly over 10 layers
-    assert max(errs.values()) < 5e-3, errs
+    print("bf16 %s: free-running emb %.2e; teacher-forced gradient worst %.2e" % (net, e_free, max(errs.values())))
+    # ~1e-5 at fc1, growing towards the input: a one-ulp difference in a bf16-stored gradient spreads over the 9*cin inputs of the
+    # next data-gradient, some of which cross their own rounding boundary, ... until the difference saturates at the bf16 noise of
+    # the gradients themselves (2.5e-3 over LightCNN-9's 10 layers, 1.2e-2 over the deeper CNN's 14).  A wiring or rounding-point
+    # error would be O(1), and visible at fc1 first.
+    assert max(errs.values()) < 2e-2, errs
     assert errs['fc1_weight'] < 1e-4 and errs['fc1_bias'] < 1e-4
+    last = convs[-2].pname
+    assert errs[last + '_weight'] < 1e-3 and errs[last + '_bias'] < 1e-3, (last, errs[last + '_weight'])
     tr.backward()
     assert torch.isfinite(tr.grad).all()
     tr.update()

@@ -69,3 +69,31 @@ def test_lightcnn9_semihard_step_vs_oracle():
     worst = max(rel_err(g[k].cpu().numpy().reshape(tp[k].shape), tp[k].grad.numpy()) for k in tp)
     assert worst < 2e-2, worst  # fp32 arg-max route flips through 10 MFM/pool stages (see test_e2e_gpu.py); forward is 1e-3
     tr.update()
+
+
+def test_deepcnn_structure_and_step_vs_oracle():
+    """BASELINE configs[4]'s build-defined deeper CNN (512-d) in fp32: structure, then one semi-hard step against the torch oracle."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
+    from improving_face_recognition_performance_using_triplet_loss_amd.plan import Plan
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
+    plan = Plan(efm_symbol.deepcnn_embedding_net(), (2, 3, 112, 112))
+    assert len([s for s in plan.steps if s.op == "conv"]) == 14 and plan.fused == 14
+    assert plan.outputs[0].shape == (512, 1, 1)
+    assert plan.flops_fwd // 2 == 5199839232
+    batch, image = 8, 32
+    tr = MiningTripletTrainer(batch, image=image, outputs=efm_symbol.deepcnn_embedding_net(), seed=11)
+    labels = (np.arange(batch) // 2).astype(np.int32)
+    tr.set_labels(labels)
+    params = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.export_params(tr.flat).items()}
+    x = O.uniform01(batch * 3 * image * image, 6).reshape(batch, 3, image, image)
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+    pos, _ = O.mining_indices(labels)
+    loss_r, emb_r, neg_r = OT.mining_step(OT.deepcnn_forward, tp, torch.tensor(x), labels, pos, 0.2)
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg_idx=torch.as_tensor(neg_r.astype(np.int32)).cuda())
+    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r.numpy()) < 1e-3
+    assert rel_err(loss.cpu().numpy(), loss_r.numpy()) < 1e-3
+    tr.backward()
+    g = tr.plan.export_params(tr.grad)
+    worst = max(rel_err(g[k].cpu().numpy().reshape(tp[k].shape), tp[k].grad.numpy()) for k in tp)
+    assert worst < 3e-2, worst  # fp32 arg-max route flips through 14 MFM/pool stages; forward is 1e-3
+    tr.update()
