@@ -436,3 +436,31 @@ def convb_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=F
     check(lib.efm_convb_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), int(bool(accumulate)), _p(ws),
                                    ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_convb_bwd_weight")
     return dw, (dbias if want_bias else None)
+
+
+# ---- Winograd F(2x2, 3x3) form of the 3x3 / pad 1 convolutions ----------------------------------------------------------
+def wino_supported(d):
+    return bool(_lib.load().efm_wino_supported(ctypes.byref(d)))
+
+
+def wino_make_u(d, w, dgrad=False, out=None):
+    """Transformed weights U = G g G^T from the packed fp32 weights (dgrad: from the data-gradient weights)."""
+    _need_dev(w)
+    n = _lib.load().efm_wino_u_elems(ctypes.byref(d), 1 if dgrad else 0)
+    u = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w.device)
+    check(_lib.load().efm_wino_make_u(ctypes.byref(d), _p(w), _p(u), 1 if dgrad else 0, _stream()), "efm_wino_make_u")
+    return u
+
+
+def wino_fwd(d, x, u, bias=None, residual=None, out=None):
+    _need_dev(x, u)
+    y = out if out is not None else torch.empty((d.batch, d.hout, d.wout, d.cout_p), dtype=torch.float32, device=x.device)
+    check(_lib.load().efm_wino_fwd(ctypes.byref(d), _p(x), _p(u), _p(bias), _p(residual), _p(y), _stream()), "efm_wino_fwd")
+    return y
+
+
+def wino_bwd_data(d, dy, u_dgrad, add=None, out=None):
+    _need_dev(dy, u_dgrad)
+    dx = out if out is not None else torch.empty((d.batch, d.hin, d.win, d.cin_p), dtype=torch.float32, device=dy.device)
+    check(_lib.load().efm_wino_bwd_data(ctypes.byref(d), _p(dy), _p(u_dgrad), _p(add), _p(dx), _stream()), "efm_wino_bwd_data")
+    return dx

@@ -173,6 +173,21 @@ int efm_maxpool2_fwd(const float* x, float* y, int batch, int h, int w, int c, v
 int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) form of the 3x3 / pad 1 / stride 1 convolutions (same call sites as efm_conv_fwd / efm_conv_bwd_data:
+ * efm_symbol.py:32,41,54,65,67) — 2.25x fewer multiplies, fp32, input / output transforms fused into the kernel.
+ * `u` = transformed weights [16][rows][k], made from the packed fp32 weights (dgrad = 0) or from the data-gradient
+ * weights of efm_conv_make_dgrad_weights (dgrad = 1) whenever the weights change; efm_wino_u_elems floats.
+ * Results equal the direct kernels' to fp32 rounding (different summation order), not bitwise.
+ */
+int efm_wino_supported(const efm_conv_desc* d);
+size_t efm_wino_u_elems(const efm_conv_desc* d, int dgrad);
+int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int dgrad, void* stream);
+int efm_wino_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, const float* residual,
+                 float* y, void* stream);
+int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dgrad, const float* add, float* dx,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Embedding head / loss (dense row-major matrices, leading dimension = ld* floats).
  * ------------------------------------------------------------------------------------ */
 /* ref: train_efm.py:241 (FROBENIUS), final_efm.py:240-243 (ROW).  norm_out: [rows] (ROW) or [1]. */

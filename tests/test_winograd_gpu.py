@@ -1,0 +1,63 @@
+"""Winograd F(2x2, 3x3) kernels (efm_wino_*) against the NumPy fp64 oracle and the direct implicit-GEMM kernels.
+Tolerance: 2e-4 of the largest reference magnitude like every conv kernel test (measured ~1e-6: the transforms only add / halve)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import efm_oracle as O
+from tests.util import dev, from_nhwc, rand, rel_err, to_nhwc
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+# (batch, h, w, cin, cout): even / odd maps (7 -> 4 tiles with a half-empty last one), channel counts off the 4 / 8 / 16 grids,
+# 1..3 channel blocks, tile counts that are not a multiple of 32
+CASES = [(2, 8, 8, 8, 16), (3, 14, 14, 44, 99), (2, 7, 7, 174, 261), (1, 28, 28, 66, 66), (2, 6, 10, 5, 35), (1, 56, 56, 12, 198),
+         (5, 7, 5, 258, 387)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_fwd_and_dgrad(case):
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w, cin, cout = case
+    x = rand((b, cin, h, w), 1)
+    wt = rand((cout, cin, 3, 3), 2, 0.2)
+    bias = rand((cout,), 3)
+    d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+    assert ops.wino_supported(d)
+    xd = to_nhwc(x)
+    wp = ops.conv_pack_weights(d, dev(wt))
+    bp = torch.zeros(d.n_pad16, device="cuda")
+    bp[:cout] = dev(bias)
+    ref = O.conv2d(x, wt, bias, (1, 1))
+    u = ops.wino_make_u(d, wp)
+    y = ops.wino_fwd(d, xd, u, bp)
+    assert rel_err(from_nhwc(y, cout), ref) < TOL
+    if d.cout_p > cout:
+        assert float(y[..., cout:].abs().max()) == 0.0      # pad channels stay zero
+    assert rel_err(y.cpu().numpy(), ops.conv_fwd(d, xd, wp, bp).cpu().numpy()) < 1e-5   # vs the direct kernel
+    res = rand(ref.shape, 4)
+    y2 = ops.wino_fwd(d, xd, u, bp, residual=to_nhwc(res))
+    assert rel_err(from_nhwc(y2, cout), ref + res) < TOL
+    # data gradient = the same kernel on dy with U made from the tap-flipped transposed weights
+    dy = rand(ref.shape, 5)
+    dx_ref, _, _ = O.conv2d_bwd(x, wt, dy, (1, 1))
+    dyd = to_nhwc(dy)
+    ud = ops.wino_make_u(d, ops.conv_make_dgrad_weights(d, wp), dgrad=True)
+    dx = ops.wino_bwd_data(d, dyd, ud)
+    assert rel_err(from_nhwc(dx, cin), dx_ref) < TOL
+    if d.cin_p > cin:
+        assert float(dx[..., cin:].abs().max()) == 0.0
+    add = rand(x.shape, 6)
+    dx2 = ops.wino_bwd_data(d, dyd, ud, add=to_nhwc(add))
+    assert rel_err(from_nhwc(dx2, cin), dx_ref + add) < TOL
+
+
+def test_wino_rejects_other_geometries():
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    assert not ops.wino_supported(ops.conv_desc(1, 8, 8, 4, 4, 1, 1, 0, 0))
+    assert not ops.wino_supported(ops.conv_desc(1, 8, 8, 4, 4, 5, 5, 2, 2))
+    assert not ops.wino_supported(ops.conv_desc(1, 8, 8, 4, 4, 3, 3, 0, 0))
+    d = ops.conv_desc(1, 8, 8, 4, 4, 5, 5, 2, 2)
+    with pytest.raises(Exception):
+        ops.wino_make_u(d, torch.zeros(d.n_pad16 * d.k_pad, device="cuda"))

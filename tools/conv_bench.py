@@ -73,7 +73,7 @@ def main():
         flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
         line = "%-14s %3dx%-3d %3d->%-3d k%d M=%-7d" % (st.pname, d.hin, d.win, d.cin, d.cout, d.kh, d.batch * d.hout * d.wout)
         for k in what:
-            if k == "dgrad" and not st.inputs[0].needs_grad:
+            if k in ("dgrad", "wdgrad") and not st.inputs[0].needs_grad:
                 line += "  dgrad   --           "
                 continue
             if bf:
@@ -86,6 +86,15 @@ def main():
                     ms = timeit(lambda: ops.convb_bwd_data(d, dyb, wdb), a.iters)
                 else:
                     ms = timeit(lambda: ops.convb_bwd_weight(d, xb, dyb, dw=dw, dbias=db), a.iters)
+            elif k in ("wfwd", "wdgrad"):
+                if not ops.wino_supported(d):
+                    continue
+                if k == "wfwd":
+                    u = ops.wino_make_u(d, w)
+                    ms = timeit(lambda: ops.wino_fwd(d, x, u, b, out=y), a.iters)
+                else:
+                    u = ops.wino_make_u(d, wd, dgrad=True)
+                    ms = timeit(lambda: ops.wino_bwd_data(d, dy, u, out=dx), a.iters)
             elif k == "fwd":
                 ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
                 if st.epi is not None:
