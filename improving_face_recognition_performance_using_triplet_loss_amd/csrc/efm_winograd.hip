@@ -26,20 +26,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define EFM_OOB 0x80000000u
 
-constexpr int TB = 32;              // tiles per block
+constexpr int TB = 64;              // tiles per block
 constexpr int KC = 8;               // channels per K chunk
-constexpr int VS = TB * KC + 8;     // floats between the xi planes of V (the +8 spreads the planes over the banks)
+constexpr int V_STAGE = 16 * TB * KC;  // floats: V[xi][row][8], row = tile ^ ((xi & 3) << 1) (spreads the 4 planes a quad writes over the banks)
 
 struct WinoP {
   const float* x;
-  const float* u;     // [16][n_rows][kpad]
+  const float* u;     // [channel block][16 xi][NB rows][kpad]
   const float* bias;  // may be null
   const float* res;   // may be null: added to y (residual / skip gradient)
   float* y;
   int batch, h, w, cin_p, cout_p;
   int th, tw, tiles;  // tile grid per image, total tiles
-  int n_rows, kpad, chunks, nblocks;
+  int kpad, chunks, nblocks;
   unsigned x_bytes, u_bytes;
+  int dbg;
 };
 
 template <int CTRL>
@@ -47,45 +48,44 @@ __device__ __forceinline__ float quad(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// Block = 512 threads = 8 waves = 64 tiles x (16*NTB) output channels x all 16 xi.  The kernel is bound by the bytes in flight
+// between L2 and LDS (a chunk is consumed in ~2 us, a load takes ~2.6 us under load, and LDS holds two stages), so the tile is
+// as large as the 160 KB of LDS and the 256 registers per lane allow (the U chunk, 16*NB*8 floats, is shared by 64 tiles), and the
+// pipeline is three deep on the x side: iteration c issues the patch loads of chunk c+2, transforms chunk c+1 (loaded during
+// iteration c-1) into the free V stage while the MFMAs of chunk c run.
 template <int NTB>
 __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
   constexpr int NB = 16 * NTB;
-  constexpr int V_STAGE = 16 * VS, U_STAGE = 16 * NB * KC, STAGE = V_STAGE + U_STAGE;
+  constexpr int U_STAGE = 16 * NB * KC, STAGE = V_STAGE + U_STAGE;
   constexpr int RS = NB + 4;  // row stride of the epilogue exchange buffer (floats): 4*RS % 32 == 16 spreads the 4 row groups over the banks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wh = wave & 1;
   const int fi = lane & 15, fq = lane >> 4;
   const int nb = (int)blockIdx.x % p.nblocks, tb = (int)blockIdx.x / p.nblocks;
   const int t0 = tb * TB, n0 = nb * NB;
+  const int per = p.th * p.tw;
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
 
-  // ---- input-transform coordinates (waves 0..3): thread = (tile tt, channel group q, patch column c); c = lane & 3 (a DPP quad)
-  const bool xf = tid < 256;
-  const int tt = (tid >> 3) & 31, q = (tid >> 2) & 1, c = tid & 3;
+  // ---- input-transform coordinates: thread = (tile tt, channel group q, patch column c); c = lane & 3 (a DPP quad)
+  const int tt = tid >> 3, q = (tid >> 2) & 1, c = tid & 3;
   unsigned xoff[4];
   {
     const int tile = t0 + tt;
-    const int per = p.th * p.tw;
     const int b = tile / per, r = tile - b * per;
     const int ty = r / p.tw, tx = r - ty * p.tw;
     const int ix = 2 * tx - 1 + c;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int iy = 2 * ty - 1 + rr;
-      const bool ok = xf && tile < p.tiles && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
+      const bool ok = tile < p.tiles && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
       xoff[rr] = ok ? (unsigned)((((b * p.h + iy) * p.w + ix) * p.cin_p + q * 4) * 4) : EFM_OOB;
     }
   }
-  // ---- U staging: wave issues NTB LDS-DMA instructions per chunk, each 32 rows (xi, n) x 2 pieces of 16 bytes
-  unsigned uoff[NTB];
-#pragma unroll
-  for (int j = 0; j < NTB; ++j) {
-    const int row = 32 * (wave * NTB + j) + (lane >> 1);
-    const int xi = row / NB, n = row - xi * NB;
-    uoff[j] = (unsigned)((((xi * p.n_rows + n0 + n) * p.kpad) + (lane & 1) * 4) * 4);
-  }
+  // ---- U staging: a wave issues NTB LDS-DMA instructions per chunk, each 32 consecutive rows of this block's [16 xi][NB] x 2 pieces
+  const unsigned ubase = (unsigned)(((((nb * 16 * NB) + 32 * wave * NTB + (lane >> 1)) * p.kpad) + (lane & 1) * 4) * 4);
+  const unsigned ustep = (unsigned)(32 * p.kpad * 4);
 
   u32x4 xreg[4];
   auto load_x = [&](int ch) {
@@ -99,16 +99,16 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
 #pragma unroll
     for (int j = 0; j < NTB; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Us + (wave * NTB + j) * 256), 16,
-                                               uoff[j] + (unsigned)(ch * KC * 4), 0, 0, 0);
+                                               ubase + (unsigned)j * ustep + (unsigned)(ch * KC * 4), 0, 0, 0);
   };
   // B^T d B for 4 channels; this lane ends with column j = c of every row i and stores V[4i + c][tt][4q..4q+3]
   auto transform = [&](int buf) {
-    if (!xf) return;
     float* Vs = smem + buf * STAGE;
     f32x4 d0 = __builtin_bit_cast(f32x4, xreg[0]), d1 = __builtin_bit_cast(f32x4, xreg[1]);
     f32x4 d2 = __builtin_bit_cast(f32x4, xreg[2]), d3 = __builtin_bit_cast(f32x4, xreg[3]);
     f32x4 t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
     const float sg = (c == 1) ? 1.f : -1.f;
+    const int vrow = (tt ^ (c << 1)) * KC + q * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v;
@@ -119,15 +119,17 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
         const float s = quad<0xDA>(t[i][e]);   // quad_perm [2,2,1,3]
         v[e] = a + sg * s;
       }
-      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * VS + tt * KC + q * 4) = v;
+      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC) + vrow) = v;
     }
   };
 
-  f32x4 acc[4][NTB];
+  f32x4 acc[4][2][NTB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < NTB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int b = 0; b < NTB; ++b) acc[a][m][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
     const float* Vs = smem + buf * STAGE;
@@ -135,87 +137,106 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
 #pragma unroll
     for (int jx = 0; jx < 4; ++jx) {
       const int xi = 4 * wi + jx;
-      const f32x2 a = *reinterpret_cast<const f32x2*>(Vs + xi * VS + (wh * 16 + fi) * KC + fq * 2);
+      f32x2 a[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt] = *reinterpret_cast<const f32x2*>(Vs + xi * (TB * KC) + ((wh * 32 + mt * 16 + fi) ^ (jx << 1)) * KC + fq * 2);
 #pragma unroll
       for (int nt = 0; nt < NTB; ++nt) {
         const f32x2 b = *reinterpret_cast<const f32x2*>(Us + ((xi * NB + nt * 16 + fi) * KC) + fq * 2);
-        acc[jx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[jx][nt], 0, 0, 0);
-        acc[jx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[jx][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[jx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][0], b[0], acc[jx][mt][nt], 0, 0, 0);
+          acc[jx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][1], b[1], acc[jx][mt][nt], 0, 0, 0);
+        }
       }
     }
   };
 
-  load_x(0);
-  dma_u(0, 0);
-  transform(0);
+  const bool dx_ = !(p.dbg & 1), du_ = !(p.dbg & 2), dc_ = !(p.dbg & 4);
+  if (dx_) load_x(0);
+  if (du_) dma_u(0, 0);
+  if (dx_) transform(0);
+  if (dx_ && p.chunks > 1) load_x(1);
   __syncthreads();
   for (int ch = 0; ch < p.chunks; ++ch) {
     const bool more = ch + 1 < p.chunks;
-    if (more) {
-      dma_u(ch + 1, (ch + 1) & 1);
-      load_x(ch + 1);
-    }
-    compute(ch & 1);
-    if (more) transform((ch + 1) & 1);
+    if (more && du_) dma_u(ch + 1, (ch + 1) & 1);
+    if (more && dx_) transform((ch + 1) & 1);            // x(ch+1) was loaded during the previous iteration
+    if (ch + 2 < p.chunks && dx_) load_x(ch + 2);
+    if (dc_) compute(ch & 1);
     __syncthreads();
   }
 
-  // ---- epilogue.  In registers: R_i[b] = sum_j M[i][j] * At[b][j]  (At = [1 1 1 0; 0 1 -1 -1]); through LDS: y[a][b] = sum_i At[a][i] R_i[b]
-  float* Rs = smem;  // [i][b][tile 32][RS]
-#pragma unroll
-  for (int nt = 0; nt < NTB; ++nt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
-      const int trow = wh * 16 + 4 * fq + r;
-      Rs[((wi * 2 + 0) * TB + trow) * RS + nt * 16 + fi] = m0 + m1 + m2;
-      Rs[((wi * 2 + 1) * TB + trow) * RS + nt * 16 + fi] = m1 - m2 - m3;
-    }
-  }
-  __syncthreads();
+  // ---- epilogue.  In registers: R_i[b] = sum_j M[i][j] * At[b][j]  (At = [1 1 1 0; 0 1 -1 -1]); through LDS, one output column b
+  // per pass: y[a][b] = sum_i At[a][i] R_i[b]
+  float* Rs = smem;  // [i][tile 64][RS]
   constexpr int NQ = NB / 4;
-  const int per = p.th * p.tw;
-  for (int it = tid; it < TB * 4 * NQ; it += 512) {
-    const int cq = it % NQ, rest = it / NQ;
-    const int pix = rest & 3, tl = rest >> 2;
-    const int a = pix >> 1, bb = pix & 1;
-    const int tile = t0 + tl, n = n0 + cq * 4;
-    if (tile >= p.tiles || n >= p.cout_p) continue;
-    const int b = tile / per, r = tile - b * per;
-    const int ty = r / p.tw, tx = r - ty * p.tw;
-    const int oy = 2 * ty + a, ox = 2 * tx + bb;
-    if (oy >= p.h || ox >= p.w) continue;
-    const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + ((1 * 2 + bb) * TB + tl) * RS + cq * 4);
-    const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + ((2 * 2 + bb) * TB + tl) * RS + cq * 4);
-    f32x4 v;
-    if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + ((0 * 2 + bb) * TB + tl) * RS + cq * 4) + r1 + r2;
-    else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + ((3 * 2 + bb) * TB + tl) * RS + cq * 4);
-    const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
-    *reinterpret_cast<f32x4*>(p.y + off) = v;
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r], m3 = acc[3][mt][nt][r];
+          const int trow = wh * 32 + mt * 16 + 4 * fq + r;
+          Rs[(wi * TB + trow) * RS + nt * 16 + fi] = (bb == 0) ? (m0 + m1 + m2) : (m1 - m2 - m3);
+        }
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < TB * 2 * NQ; it += 512) {
+      const int cq = it % NQ, rest = it / NQ;
+      const int a = rest & 1, tl = rest >> 1;
+      const int tile = t0 + tl, n = n0 + cq * 4;
+      if (tile >= p.tiles || n >= p.cout_p) continue;
+      const int b = tile / per, r = tile - b * per;
+      const int ty = r / p.tw, tx = r - ty * p.tw;
+      const int oy = 2 * ty + a, ox = 2 * tx + bb;
+      if (oy >= p.h || ox >= p.w) continue;
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
+      const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + (2 * TB + tl) * RS + cq * 4);
+      f32x4 v;
+      if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + (0 * TB + tl) * RS + cq * 4) + r1 + r2;
+      else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + (3 * TB + tl) * RS + cq * 4);
+      const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
+      *reinterpret_cast<f32x4*>(p.y + off) = v;
+    }
+    if (bb == 0) __syncthreads();
   }
 }
 
 template <int NTB>
 __global__ void __launch_bounds__(512, 1) wino_fwd_k(const WinoP p) {
-  constexpr int STAGE = 16 * VS + 16 * 16 * NTB * KC;
-  constexpr int EPI = 8 * TB * (16 * NTB + 4);
+  constexpr int STAGE = V_STAGE + 16 * 16 * NTB * KC;
+  constexpr int EPI = 4 * TB * (16 * NTB + 4);
   __shared__ __attribute__((aligned(16))) float smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
   wino_body<NTB>(p, smem);
 }
 
-// U[xi = 4i + j][n][ci] = sum_{pq} G[i][p] g[p][q] G[j][q], g[p][q] = w[n][(p*3 + q)*cin_p + ci];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int n_src, int k_pad_src, int cin_p,
-                                                int n_rows, int kpad) {
+// U[channel block][xi = 4i + j][row][k] = sum_{pq} G[i][p] g[p][q] G[j][q];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
+// forward:       row n = output channel, k = input channel,  g[p][q] = w[n][(p*3 + q)*cin_p + k]
+// data gradient: row n = input channel,  k = output channel, g[p][q] = w[k][((2-p)*3 + (2-q))*cin_p + n]   (tap-flipped transpose)
+// both read the packed forward weights w[n_pad16][k_pad].  One thread per (n, k).
+__global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin, int k_pad_src,
+                                                int cin_p, int n_rows, int nbr, int kpad) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)n_rows * kpad) return;
-  const int n = (int)(i / kpad), ci = (int)(i - (long)n * kpad);
+  const int n = (int)(i / kpad), k = (int)(i - (long)n * kpad);
+  const bool ok = dgrad ? (n < cin && k < cout) : (n < cout && k < cin);
   float g[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) g[a][b] = (n < n_src && ci < cin_p) ? w[(long)n * k_pad_src + (a * 3 + b) * cin_p + ci] : 0.f;
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (ok) v = dgrad ? w[(long)k * k_pad_src + ((2 - a) * 3 + (2 - b)) * cin_p + n] : w[(long)n * k_pad_src + (a * 3 + b) * cin_p + k];
+      g[a][b] = v;
+    }
   float t[4][3];  // G g
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
@@ -224,14 +245,15 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
+  const int blk = n / nbr, row = n - blk * nbr;
+  float* dst = u + ((long)blk * 16 * nbr + row) * kpad + k;
+  const long plane = (long)nbr * kpad;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
-    const long plane = (long)n_rows * kpad;
-    u[(4 * a + 0) * plane + i] = u0;
-    u[(4 * a + 1) * plane + i] = u1;
-    u[(4 * a + 2) * plane + i] = u2;
-    u[(4 * a + 3) * plane + i] = u3;
+    dst[(4 * a + 0) * plane] = t[a][0];
+    dst[(4 * a + 1) * plane] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    dst[(4 * a + 2) * plane] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+    dst[(4 * a + 3) * plane] = t[a][2];
   }
 }
 
@@ -239,11 +261,13 @@ struct WinoPlan {
   int NTB, nblocks, n_rows, kpad;
 };
 
-// output-channel tiles per block: as few blocks as possible with at most 7 tiles each
+// output-channel tiles per block: as few blocks as possible with at most EFM_WINO_NTB (default 5) tiles each
+// (two stages of V 32 KB + U 8*NTB KB must fit the 160 KB of LDS, 32*NTB accumulator registers the 256 per lane)
 WinoPlan plan_wino(int cin_p, int cout) {
   WinoPlan pl;
   const int tiles = (cout + 15) / 16;
-  pl.nblocks = (tiles + 6) / 7;
+  static const int max_ntb = [] { const char* e = getenv("EFM_WINO_NTB"); return e ? atoi(e) : 5; }();
+  pl.nblocks = (tiles + max_ntb - 1) / max_ntb;
   pl.NTB = std::max(3, (tiles + pl.nblocks - 1) / pl.nblocks);
   pl.n_rows = pl.nblocks * pl.NTB * 16;
   pl.kpad = (cin_p + KC - 1) / KC * KC;
@@ -257,16 +281,17 @@ int run_wino(const float* x, const float* u, const float* bias, const float* res
   p.x = x; p.u = u; p.bias = bias; p.res = res; p.y = y;
   p.batch = batch; p.h = h; p.w = w; p.cin_p = cin_p; p.cout_p = cout_p;
   p.th = (h + 1) / 2; p.tw = (w + 1) / 2; p.tiles = batch * p.th * p.tw;
-  p.n_rows = pl.n_rows; p.kpad = pl.kpad; p.chunks = pl.kpad / KC; p.nblocks = pl.nblocks;
+  p.kpad = pl.kpad; p.chunks = pl.kpad / KC; p.nblocks = pl.nblocks;
   p.x_bytes = (unsigned)((size_t)batch * h * w * cin_p * 4);
   p.u_bytes = (unsigned)((size_t)16 * pl.n_rows * pl.kpad * 4);
+  { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
   dim3 grid((unsigned)(efm::cdiv(p.tiles, TB) * pl.nblocks));
   switch (pl.NTB) {
 #define EFM_CASE(N)                                                        \
   case N:                                                                  \
     hipLaunchKernelGGL((wino_fwd_k<N>), grid, dim3(512), 0, s, p);         \
     break;
-    EFM_CASE(3) EFM_CASE(4) EFM_CASE(5) EFM_CASE(6) EFM_CASE(7)
+    EFM_CASE(3) EFM_CASE(4) EFM_CASE(5) EFM_CASE(6)
 #undef EFM_CASE
     default:
       efm::set_error("wino: unsupported NTB=%d", pl.NTB);
@@ -290,12 +315,10 @@ size_t efm_wino_u_elems(const efm_conv_desc* d, int dgrad) {
 
 int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int dgrad, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && w_packed && u, "wino_make_u: unsupported descriptor or null argument");
-  // dgrad: w_packed is the tap-flipped transposed matrix of efm_conv_make_dgrad_weights: rows = cin, k = tap*cout_p + co
   const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin) : plan_wino(d->cin_p, d->cout);
-  const int n_src = dgrad ? d->dn_pad16 : d->n_pad16, k_src = dgrad ? d->dk_pad : d->k_pad, cp = dgrad ? d->cout_p : d->cin_p;
   const long total = (long)pl.n_rows * pl.kpad;
-  hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, n_src, k_src, cp,
-                     pl.n_rows, pl.kpad);
+  hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, dgrad ? 1 : 0, d->cout,
+                     d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad);
   return efm::check_launch("wino_make_u");
 }
 

@@ -444,7 +444,7 @@ def wino_supported(d):
 
 
 def wino_make_u(d, w, dgrad=False, out=None):
-    """Transformed weights U = G g G^T from the packed fp32 weights (dgrad: from the data-gradient weights)."""
+    """Transformed weights U = G g G^T from the packed fp32 weights (dgrad: their tap-flipped transpose, for wino_bwd_data)."""
     _need_dev(w)
     n = _lib.load().efm_wino_u_elems(ctypes.byref(d), 1 if dgrad else 0)
     u = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w.device)

@@ -328,7 +328,11 @@ class Plan:
                                                                      st.epi["order"], st.epi["pool"])
                     continue
                 res = acts[st.residual.index] if st.residual is not None else None
-                acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
+                if getattr(st, "wino_fwd", False):  # Winograd F(2x2,3x3): chosen by autotune() where it is faster
+                    st.u_fwd = ops.wino_make_u(st.desc, w, out=getattr(st, "u_fwd", None))
+                    acts[st.index] = ops.wino_fwd(st.desc, acts[st.inputs[0].index], st.u_fwd, bias, res)
+                else:
+                    acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
             elif st.op == "mfm":
                 acts[st.index] = ops.mfm_fwd(acts[st.inputs[0].index], st.inputs[0].shape[0], st.node.attrs["ways"])
             elif st.op == "pool":
@@ -408,6 +412,10 @@ class Plan:
                 if bf and src.needs_grad:
                     prev = gr.pop(src.index, None)
                     gr[src.index] = ops.convb_bwd_data(d, dy, st.wdb, add=prev)
+                elif getattr(st, "wino_dgrad", False) and src.needs_grad:
+                    st.u_dgrad = ops.wino_make_u(d, v[wname], dgrad=True, out=getattr(st, "u_dgrad", None))
+                    prev = gr.pop(src.index, None)
+                    gr[src.index] = ops.wino_bwd_data(d, dy, st.u_dgrad, add=prev)
                 elif src.needs_grad or (src.op == "input" and need_input_grad):
                     wd = self._wd_scratch[: d.dn_pad16 * d.dk_pad]
                     ops.conv_make_dgrad_weights(d, v[wname], out=wd)
@@ -451,7 +459,9 @@ class Plan:
     def autotune(self, iters=3, verbose=False):
         """Time the tiling candidates (64/128-pixel tiles x 1..3 channel blocks) of every plain convolution forward and
         data gradient at this plan's shapes and store the winners in the descriptors (results are bit-identical for every
-        choice).  ~1 s at B = 256; idempotent."""
+        choice).  For the 3x3 / pad 1 layers the Winograd F(2x2,3x3) kernels (plain forward and data gradient) are timed
+        against the winner and taken where at least 3 % faster — those layers then differ from the direct kernels by fp32
+        rounding (~1e-6), not bitwise; EFM_WINO=0 keeps the direct kernels everywhere.  ~1 s at B = 256; idempotent."""
         if self.device.type != "cuda":
             return {}
         chosen = {}
@@ -475,6 +485,18 @@ class Plan:
             setattr(d, field, win)
             return win, times
 
+        def timed(run):
+            run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                run()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+
+        wino = self.dtype == "f32" and os.environ.get("EFM_WINO", "1") != "0"
+        force = os.environ.get("EFM_WINO") == "force"  # tests: Winograd wherever it applies, whatever the clock says
         seen = {}
         for st in self.steps:
             if st.op != "conv":
@@ -482,14 +504,21 @@ class Plan:
             d = st.desc
             key = (d.hin, d.win, d.cin, d.cout, d.kh, d.pad_h, st.epi is not None, st.inputs[0].needs_grad)
             if key in seen:
-                d.tune_fwd, d.tune_dgrad = seen[key]
+                d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad = seen[key]
                 continue
+            st.wino_fwd = st.wino_dgrad = False
             x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=self.device)
             dy = torch.rand((d.batch, d.hout, d.wout, d.cout_p), device=self.device)
             if st.epi is None:
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 y = torch.empty_like(dy)
-                chosen[st.pname + ":fwd"] = best(lambda: ops.conv_fwd(d, x, w, None, out=y), d, "tune_fwd")[0]
+                win, times = best(lambda: ops.conv_fwd(d, x, w, None, out=y), d, "tune_fwd")
+                chosen[st.pname + ":fwd"] = win
+                if wino and ops.wino_supported(d):
+                    u = ops.wino_make_u(d, w)
+                    if timed(lambda: ops.wino_fwd(d, x, u, None, out=y)) < 0.97 * times[win] or force:
+                        st.wino_fwd = True
+                        chosen[st.pname + ":fwd"] = "winograd"
             else:  # fused epilogue: number of channel blocks
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 e = st.epi
@@ -498,8 +527,14 @@ class Plan:
             if st.inputs[0].needs_grad:
                 wd = torch.rand((d.dn_pad16, d.dk_pad), device=self.device)
                 dx = torch.empty_like(x)
-                chosen[st.pname + ":dgrad"] = best(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), d, "tune_dgrad")[0]
-            seen[key] = (d.tune_fwd, d.tune_dgrad)
+                win, times = best(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), d, "tune_dgrad")
+                chosen[st.pname + ":dgrad"] = win
+                if wino and ops.wino_supported(d):
+                    u = ops.wino_make_u(d, torch.rand((d.n_pad16, d.k_pad), device=self.device), dgrad=True)
+                    if timed(lambda: ops.wino_bwd_data(d, dy, u, out=dx)) < 0.97 * times[win] or force:
+                        st.wino_dgrad = True
+                        chosen[st.pname + ":dgrad"] = "winograd"
+            seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad)
         if verbose:
             print("[efm autotune]", {k: v for k, v in chosen.items() if v})
         return chosen

@@ -175,8 +175,8 @@ int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int 
 /* ------------------------------------------------------------------------------------
  * Winograd F(2x2, 3x3) form of the 3x3 / pad 1 / stride 1 convolutions (same call sites as efm_conv_fwd / efm_conv_bwd_data:
  * efm_symbol.py:32,41,54,65,67) — 2.25x fewer multiplies, fp32, input / output transforms fused into the kernel.
- * `u` = transformed weights [16][rows][k], made from the packed fp32 weights (dgrad = 0) or from the data-gradient
- * weights of efm_conv_make_dgrad_weights (dgrad = 1) whenever the weights change; efm_wino_u_elems floats.
+ * `u` = transformed weights U = G g G^T, made from the packed fp32 weights of efm_conv_pack_weights whenever they change:
+ * dgrad = 0 for efm_wino_fwd, dgrad = 1 (tap-flipped transpose) for efm_wino_bwd_data; efm_wino_u_elems(d, dgrad) floats.
  * Results equal the direct kernels' to fp32 rounding (different summation order), not bitwise.
  */
 int efm_wino_supported(const efm_conv_desc* d);

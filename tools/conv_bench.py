@@ -93,7 +93,7 @@ def main():
                     u = ops.wino_make_u(d, w)
                     ms = timeit(lambda: ops.wino_fwd(d, x, u, b, out=y), a.iters)
                 else:
-                    u = ops.wino_make_u(d, wd, dgrad=True)
+                    u = ops.wino_make_u(d, w, dgrad=True)
                     ms = timeit(lambda: ops.wino_bwd_data(d, dy, u, out=dx), a.iters)
             elif k == "fwd":
                 ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
