@@ -799,7 +799,7 @@ int run_fwd(const void* x, const void* w, const float* bias, const void* res, vo
   p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0; p.cpo = 0; p.out_f32 = 1;
   const int tiles = n_pad16 / 16;
   int nblocks = (tiles + 12) / 13;
-  if ((tune >> 4) > nblocks) nblocks = std::min(tune >> 4, tiles);
+  if (((tune >> 4) & 15) > nblocks) nblocks = std::min((tune >> 4) & 15, tiles);  // bits 9:8 belong to the Winograd kernels
   const int NT = round_nt((tiles + nblocks - 1) / nblocks);
   p.nblocks = (tiles + NT - 1) / NT;
   // 64-row tiles (52 accumulator registers at NT = 13 -> 4 blocks per CU) measured equal or better than 128-row
@@ -1233,7 +1233,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default (measured on EFM-29): one block up
   // to 13 column tiles, two above (387- and 261-channel layers: 13- / 9-tile blocks beat one 25- / 17-tile block).
   const int cs_all = d->cout / ways;
-  int nsplit = env_int("EFM_EPI_NSPLIT", d->tune_fwd >> 4);
+  int nsplit = env_int("EFM_EPI_NSPLIT", (d->tune_fwd >> 4) & 15);
   if (nsplit <= 0) nsplit = (ways * cs_all > 13 * 16) ? 2 : 1;
   nsplit = std::min(nsplit, cs_all);
   int cn = (cs_all + nsplit - 1) / nsplit;
@@ -1379,7 +1379,7 @@ int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t*
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "convb_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "convb_mfm_fwd: bad order %d", order);
   const int cs_all = d->cout / ways;
-  int nsplit = d->tune_fwd >> 4;
+  int nsplit = (d->tune_fwd >> 4) & 15;
   if (nsplit <= 0) nsplit = (ways * cs_all > 13 * 16) ? 2 : 1;
   nsplit = std::min(nsplit, cs_all);
   int cn = (cs_all + nsplit - 1) / nsplit;

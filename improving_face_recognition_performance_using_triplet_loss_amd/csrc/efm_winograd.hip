@@ -218,6 +218,165 @@ __global__ void __launch_bounds__(512, 1) wino_fwd_k(const WinoP p) {
   wino_body<NTB>(p, smem);
 }
 
+// ---- 4-wave variant: two blocks per CU.  Block = 256 threads = 64 tiles x (16*NTB <= 48) channels x 16 xi, K chunk = 4 channels,
+// wave i owns xi = 4i..4i+3 for all 64 tiles (16*NTB accumulator tiles); 2 stages of (V 16 KB + U 4*NTB KB) = 56 KB at NTB = 3,
+// so two blocks share a CU and cover each other's load latency, barriers and epilogues.
+constexpr int KC4 = 4;
+constexpr int V4_STAGE = 16 * TB * KC4;  // floats: V[xi][row][4], row = tile ^ ((xi & 3) << 1)
+
+template <int NTB>
+__device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
+  constexpr int NB = 16 * NTB;
+  constexpr int U_STAGE = 16 * NB * KC4, STAGE = V4_STAGE + U_STAGE;
+  constexpr int RS = NB + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+  const int fi = lane & 15, fq = lane >> 4;
+  const int nb = (int)blockIdx.x % p.nblocks, tb = (int)blockIdx.x / p.nblocks;
+  const int t0 = tb * TB, n0 = nb * NB;
+  const int per = p.th * p.tw;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+  // input transform: thread = (tile tt, patch column c)
+  const int tt = tid >> 2, c = tid & 3;
+  unsigned xoff[4];
+  {
+    const int tile = t0 + tt;
+    const int b = tile / per, r = tile - b * per;
+    const int ty = r / p.tw, tx = r - ty * p.tw;
+    const int ix = 2 * tx - 1 + c;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int iy = 2 * ty - 1 + rr;
+      const bool ok = tile < p.tiles && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w;
+      xoff[rr] = ok ? (unsigned)((((b * p.h + iy) * p.w + ix) * p.cin_p) * 4) : EFM_OOB;
+    }
+  }
+  // U staging: NTB LDS-DMA instructions per wave and chunk, each 64 consecutive rows of this block's [16 xi][NB] x 16 bytes
+  const unsigned ubase = (unsigned)((((nb * 16 * NB) + 64 * wi * NTB + lane) * p.kpad) * 4);
+  const unsigned ustep = (unsigned)(64 * p.kpad * 4);
+
+  u32x4 xreg[4];
+  auto load_x = [&](int ch) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      xreg[rr] = __builtin_amdgcn_raw_buffer_load_b128(xr, (xoff[rr] != EFM_OOB) ? xoff[rr] + (unsigned)(ch * KC4 * 4) : EFM_OOB, 0, 0);
+  };
+  auto dma_u = [&](int ch, int buf) {
+    float* Us = smem + buf * STAGE + V4_STAGE;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Us + (wi * NTB + j) * 256), 16,
+                                               ubase + (unsigned)j * ustep + (unsigned)(ch * KC4 * 4), 0, 0, 0);
+  };
+  auto transform = [&](int buf) {
+    float* Vs = smem + buf * STAGE;
+    f32x4 d0 = __builtin_bit_cast(f32x4, xreg[0]), d1 = __builtin_bit_cast(f32x4, xreg[1]);
+    f32x4 d2 = __builtin_bit_cast(f32x4, xreg[2]), d3 = __builtin_bit_cast(f32x4, xreg[3]);
+    f32x4 t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+    const float sg = (c == 1) ? 1.f : -1.f;
+    const int vrow = (tt ^ (c << 1)) * KC4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = quad<0x64>(t[i][e]);   // quad_perm [0,1,2,1]
+        const float s = quad<0xDA>(t[i][e]);   // quad_perm [2,2,1,3]
+        v[e] = a + sg * s;
+      }
+      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC4) + vrow) = v;
+    }
+  };
+
+  f32x4 acc[4][4][NTB];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int b = 0; b < NTB; ++b) acc[a][m][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const float* Vs = smem + buf * STAGE;
+    const float* Us = Vs + V4_STAGE;
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      const int xi = 4 * wi + jx;
+      float a[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = Vs[xi * (TB * KC4) + ((mt * 16 + fi) ^ (jx << 1)) * KC4 + fq];
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+        const float b = Us[(xi * NB + nt * 16 + fi) * KC4 + fq];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[jx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b, acc[jx][mt][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  load_x(0);
+  dma_u(0, 0);
+  transform(0);
+  if (p.chunks > 1) load_x(1);
+  __syncthreads();
+  for (int ch = 0; ch < p.chunks; ++ch) {
+    const bool more = ch + 1 < p.chunks;
+    if (more) dma_u(ch + 1, (ch + 1) & 1);
+    if (more) transform((ch + 1) & 1);
+    if (ch + 2 < p.chunks) load_x(ch + 2);
+    compute(ch & 1);
+    __syncthreads();
+  }
+
+  float* Rs = smem;  // [i][tile 64][RS]
+  constexpr int NQ = NB / 4;
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r], m3 = acc[3][mt][nt][r];
+          Rs[(wi * TB + mt * 16 + 4 * fq + r) * RS + nt * 16 + fi] = (bb == 0) ? (m0 + m1 + m2) : (m1 - m2 - m3);
+        }
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < TB * 2 * NQ; it += 256) {
+      const int cq = it % NQ, rest = it / NQ;
+      const int a = rest & 1, tl = rest >> 1;
+      const int tile = t0 + tl, n = n0 + cq * 4;
+      if (tile >= p.tiles || n >= p.cout_p) continue;
+      const int b = tile / per, r = tile - b * per;
+      const int ty = r / p.tw, tx = r - ty * p.tw;
+      const int oy = 2 * ty + a, ox = 2 * tx + bb;
+      if (oy >= p.h || ox >= p.w) continue;
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
+      const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + (2 * TB + tl) * RS + cq * 4);
+      f32x4 v;
+      if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + (0 * TB + tl) * RS + cq * 4) + r1 + r2;
+      else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + (3 * TB + tl) * RS + cq * 4);
+      const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
+      *reinterpret_cast<f32x4*>(p.y + off) = v;
+    }
+    if (bb == 0) __syncthreads();
+  }
+}
+
+template <int NTB>
+__global__ void __launch_bounds__(256, 2) wino4_k(const WinoP p) {
+  constexpr int STAGE = V4_STAGE + 16 * 16 * NTB * KC4;
+  constexpr int EPI = 4 * TB * (16 * NTB + 4);
+  __shared__ __attribute__((aligned(16))) float smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
+  wino4_body<NTB>(p, smem);
+}
+
 // U[channel block][xi = 4i + j][row][k] = sum_{pq} G[i][p] g[p][q] G[j][q];  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].
 // forward:       row n = output channel, k = input channel,  g[p][q] = w[n][(p*3 + q)*cin_p + k]
 // data gradient: row n = input channel,  k = output channel, g[p][q] = w[k][((2-p)*3 + (2-q))*cin_p + n]   (tap-flipped transpose)
@@ -258,14 +417,31 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
 }
 
 struct WinoPlan {
-  int NTB, nblocks, n_rows, kpad;
+  int NTB, nblocks, n_rows, kpad, variant;
 };
+
+// bits 9:8 of a descriptor's tune field pick the kernel variant: 0 = default (EFM_WINO_VARIANT, else the 4-wave kernel),
+// 1 = 8-wave blocks (one per CU), 2 = 4-wave blocks (two per CU).  U's layout depends on it: make_u and the launch read the same field.
+int wino_variant(int tune) {
+  static const int dflt = [] { const char* e = getenv("EFM_WINO_VARIANT"); return e ? atoi(e) : 4; }();
+  const int v = (tune >> 8) & 3;
+  return v == 1 ? 8 : (v == 2 ? 4 : dflt);
+}
 
 // output-channel tiles per block: as few blocks as possible with at most EFM_WINO_NTB (default 5) tiles each
 // (two stages of V 32 KB + U 8*NTB KB must fit the 160 KB of LDS, 32*NTB accumulator registers the 256 per lane)
-WinoPlan plan_wino(int cin_p, int cout) {
+WinoPlan plan_wino(int cin_p, int cout, int tune) {
   WinoPlan pl;
   const int tiles = (cout + 15) / 16;
+  pl.variant = wino_variant(tune);
+  if (pl.variant == 4) {  // 4-wave blocks: 2 or 3 channel tiles per block, whichever pads less (3 on a tie)
+    const int b3 = (tiles + 2) / 3, b2 = (tiles + 1) / 2;
+    pl.NTB = (3 * b3 <= 2 * b2) ? 3 : 2;
+    pl.nblocks = (pl.NTB == 3) ? b3 : b2;
+    pl.n_rows = pl.nblocks * pl.NTB * 16;
+    pl.kpad = cin_p;
+    return pl;
+  }
   static const int max_ntb = [] { const char* e = getenv("EFM_WINO_NTB"); return e ? atoi(e) : 5; }();
   pl.nblocks = (tiles + max_ntb - 1) / max_ntb;
   pl.NTB = std::max(3, (tiles + pl.nblocks - 1) / pl.nblocks);
@@ -275,17 +451,22 @@ WinoPlan plan_wino(int cin_p, int cout) {
 }
 
 int run_wino(const float* x, const float* u, const float* bias, const float* res, float* y, int batch, int h, int w, int cin_p, int cout,
-             int cout_p, hipStream_t s) {
-  const WinoPlan pl = plan_wino(cin_p, cout);
+             int cout_p, int tune, hipStream_t s) {
+  const WinoPlan pl = plan_wino(cin_p, cout, tune);
   WinoP p;
   p.x = x; p.u = u; p.bias = bias; p.res = res; p.y = y;
   p.batch = batch; p.h = h; p.w = w; p.cin_p = cin_p; p.cout_p = cout_p;
   p.th = (h + 1) / 2; p.tw = (w + 1) / 2; p.tiles = batch * p.th * p.tw;
-  p.kpad = pl.kpad; p.chunks = pl.kpad / KC; p.nblocks = pl.nblocks;
+  p.kpad = pl.kpad; p.chunks = pl.kpad / (pl.variant == 4 ? KC4 : KC); p.nblocks = pl.nblocks;
   p.x_bytes = (unsigned)((size_t)batch * h * w * cin_p * 4);
   p.u_bytes = (unsigned)((size_t)16 * pl.n_rows * pl.kpad * 4);
   { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
   dim3 grid((unsigned)(efm::cdiv(p.tiles, TB) * pl.nblocks));
+  if (pl.variant == 4) {
+    if (pl.NTB == 3) hipLaunchKernelGGL((wino4_k<3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wino4_k<2>), grid, dim3(256), 0, s, p);
+    return efm::check_launch("wino4");
+  }
   switch (pl.NTB) {
 #define EFM_CASE(N)                                                        \
   case N:                                                                  \
@@ -309,13 +490,13 @@ int efm_wino_supported(const efm_conv_desc* d) {
 }
 
 size_t efm_wino_u_elems(const efm_conv_desc* d, int dgrad) {
-  const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin) : plan_wino(d->cin_p, d->cout);
+  const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd);
   return (size_t)16 * pl.n_rows * pl.kpad;
 }
 
 int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int dgrad, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && w_packed && u, "wino_make_u: unsupported descriptor or null argument");
-  const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin) : plan_wino(d->cin_p, d->cout);
+  const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd);
   const long total = (long)pl.n_rows * pl.kpad;
   hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, dgrad ? 1 : 0, d->cout,
                      d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad);
@@ -324,12 +505,12 @@ int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int
 
 int efm_wino_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, const float* residual, float* y, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && x && u && y, "wino_fwd: unsupported descriptor or null argument");
-  return run_wino(x, u, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->cout, d->cout_p, (hipStream_t)stream);
+  return run_wino(x, u, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->cout, d->cout_p, d->tune_fwd, (hipStream_t)stream);
 }
 
 int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dgrad, const float* add, float* dx, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && dy && u_dgrad && dx, "wino_bwd_data: unsupported descriptor or null argument");
-  return run_wino(dy, u_dgrad, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->cin, d->cin_p, (hipStream_t)stream);
+  return run_wino(dy, u_dgrad, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->cin, d->cin_p, d->tune_dgrad, (hipStream_t)stream);
 }
 
 }  // extern "C"

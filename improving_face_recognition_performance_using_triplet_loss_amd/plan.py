@@ -515,10 +515,18 @@ class Plan:
                 win, times = best(lambda: ops.conv_fwd(d, x, w, None, out=y), d, "tune_fwd")
                 chosen[st.pname + ":fwd"] = win
                 if wino and ops.wino_supported(d):
-                    u = ops.wino_make_u(d, w)
-                    if timed(lambda: ops.wino_fwd(d, x, u, None, out=y)) < 0.97 * times[win] or force:
+                    tw = {}
+                    for var in (1, 2):  # 8-wave / 4-wave kernel (bits 9:8 of the tune field; U's layout follows it)
+                        d.tune_fwd = var << 8
+                        u = ops.wino_make_u(d, w)
+                        tw[var] = timed(lambda: ops.wino_fwd(d, x, u, None, out=y))
+                    var = min(tw, key=tw.get)
+                    if tw[var] < 0.97 * times[win] or force:
                         st.wino_fwd = True
-                        chosen[st.pname + ":fwd"] = "winograd"
+                        d.tune_fwd = var << 8
+                        chosen[st.pname + ":fwd"] = "winograd/%d" % (8 if var == 1 else 4)
+                    else:
+                        d.tune_fwd = win
             else:  # fused epilogue: number of channel blocks
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 e = st.epi
@@ -530,10 +538,19 @@ class Plan:
                 win, times = best(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), d, "tune_dgrad")
                 chosen[st.pname + ":dgrad"] = win
                 if wino and ops.wino_supported(d):
-                    u = ops.wino_make_u(d, torch.rand((d.n_pad16, d.k_pad), device=self.device), dgrad=True)
-                    if timed(lambda: ops.wino_bwd_data(d, dy, u, out=dx)) < 0.97 * times[win] or force:
+                    tw = {}
+                    wf = torch.rand((d.n_pad16, d.k_pad), device=self.device)
+                    for var in (1, 2):
+                        d.tune_dgrad = var << 8
+                        u = ops.wino_make_u(d, wf, dgrad=True)
+                        tw[var] = timed(lambda: ops.wino_bwd_data(d, dy, u, out=dx))
+                    var = min(tw, key=tw.get)
+                    if tw[var] < 0.97 * times[win] or force:
                         st.wino_dgrad = True
-                        chosen[st.pname + ":dgrad"] = "winograd"
+                        d.tune_dgrad = var << 8
+                        chosen[st.pname + ":dgrad"] = "winograd/%d" % (8 if var == 1 else 4)
+                    else:
+                        d.tune_dgrad = win
             seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad)
         if verbose:
             print("[efm autotune]", {k: v for k, v in chosen.items() if v})

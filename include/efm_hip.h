@@ -178,6 +178,8 @@ int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int 
  * `u` = transformed weights U = G g G^T, made from the packed fp32 weights of efm_conv_pack_weights whenever they change:
  * dgrad = 0 for efm_wino_fwd, dgrad = 1 (tap-flipped transpose) for efm_wino_bwd_data; efm_wino_u_elems(d, dgrad) floats.
  * Results equal the direct kernels' to fp32 rounding (different summation order), not bitwise.
+ * Bits 9:8 of tune_fwd (forward) / tune_dgrad (data gradient) select the kernel variant and with it U's layout
+ * (0 default, 1 = 8-wave blocks, 2 = 4-wave blocks): keep the field unchanged between efm_wino_make_u and the launch.
  */
 int efm_wino_supported(const efm_conv_desc* d);
 size_t efm_wino_u_elems(const efm_conv_desc* d, int dgrad);
