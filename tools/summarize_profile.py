@@ -10,7 +10,7 @@ import sys
 tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)  # a re-used tag keeps older runs
 shutil.copy(stats, "profiles/%s_kernel_stats.csv" % name)
 rows = list(csv.DictReader(open(stats)))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -19,7 +19,7 @@ lines = ["# %s — rocprofv3 --kernel-trace --stats of `python3 bench.py --steps
          "bench line under the profiler: %.2f ms/step, %.1f triplets/s, dominant-kernel roofline %s" %
          (bench["ms_per_step"], bench["value"], json.dumps(bench["roofline"])), "",
          "7 steps (2 warm-up + 5 timed) + 7 extra conv2-forward launches of the roofline probe + the start-up tiling autotune "
-         "(every convolution x up to 7 candidates x 4 launches; EFM_AUTOTUNE=0 skips it); total GPU kernel time %.1f ms "
+         "(every convolution x up to 7 tilings + 2 Winograd variants x 4 launches; EFM_AUTOTUNE=0 skips it); total GPU kernel time %.1f ms "
          "(weight-gradient and data-gradient kernels overlap on two streams, so per-kernel durations add up to more than wall time)" % (total / 1e6), "",
          "| % | total ms | calls | avg us | kernel |", "|---|---|---|---|---|"]
 for r in rows[:30]:
@@ -32,17 +32,17 @@ def pmc(dirname, counter):
     if not f:
         return None
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
-            if r["Counter_Name"] == counter and "conv_fwd_k<1, 13, true, 1>" in r["Kernel_Name"]]
+            if r["Counter_Name"] == counter and "conv_fwd_k<float, 1, 13, true, 1>" in r["Kernel_Name"]]
     return vals
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
-lines += ["", "## Dominant kernel: conv2 forward = conv_fwd_k<1, 13, true, 1> (fused bias+MFM3+pool epilogue); conv2-only runs "
+lines += ["", "## Dominant kernel: conv2 forward = conv_fwd_k<float, 1, 13, true, 1> (fused bias+MFM3+pool epilogue); conv2-only runs "
           "(`tools/conv_bench.py --layers conv2 --what fwd`), separate --pmc passes", ""]
 kt = glob.glob(os.path.join(src, "pmc_fetch", "*", "*kernel_trace.csv"))
 if kt:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0]))
-            if "conv_fwd_k<1, 13, true, 1>" in r["Kernel_Name"]]
+            if "conv_fwd_k<float, 1, 13, true, 1>" in r["Kernel_Name"]]
     if durs:
         lines.append("kernel-trace duration of that instance: mean %.1f us over %d launches (min %.1f) -> %.1f TFLOP/s algorithmic"
                      % (sum(durs) / len(durs), len(durs), min(durs), 188841590784.0 / (sum(durs) / len(durs)) / 1e6))
@@ -60,7 +60,7 @@ sq = glob.glob(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv"))
 if sq:
     agg = {}
     for r in csv.DictReader(open(sq[0])):
-        if "conv_fwd_k<1, 13, true, 1>" in r["Kernel_Name"]:
+        if "conv_fwd_k<float, 1, 13, true, 1>" in r["Kernel_Name"]:
             agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     lines += ["", "## SQ counters, conv2 forward (mean per launch)", ""]
     for k, v in agg.items():
