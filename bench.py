@@ -48,9 +48,10 @@ def parse():
 
 
 def dominant_kernel_roofline(trainer, torch, iters=5):
-    """The implicit-GEMM kernel `conv_fwd_k` (forward + data gradient of every convolution) carries ~half of the step; its
-    heaviest launch is conv2 forward (66->198, 3x3, 56x56) with the fused bias+MFM+pool epilogue, instance
-    conv_fwd_k<1,13,dma,fused>.  Timed here with HIP events on the launch stream; algorithmic flops = unpadded 2*M*N*K."""
+    """The heaviest single launch of the step is conv2 forward (66->198, 3x3, 56x56) with the fused bias+MFM+pool epilogue:
+    either the direct implicit-GEMM kernel conv_fwd_k<float,1,13,dma,fused> or, where autotune found it faster, the Winograd
+    F(2x2,3x3) kernel (wino4_k / wino_fwd_k).  Timed here with HIP events on the launch stream; algorithmic flops = unpadded
+    direct-convolution 2*M*N*K (the Winograd kernel executes 2.25x fewer multiplies for the same result)."""
     from improving_face_recognition_performance_using_triplet_loss_amd import ops
     step = [s for s in trainer.plan.steps if s.op == "conv" and s.pname == "conv2"][0]
     d = step.desc
@@ -59,7 +60,14 @@ def dominant_kernel_roofline(trainer, torch, iters=5):
     x[..., d.cin:] = 0
     w, b = v["conv2_weight"], v["conv2_bias"]
     epi = step.epi or {"ways": 3, "order": 0, "pool": True}
-    run = lambda: ops.conv_mfm_fwd(d, x, w, b, epi["ways"], epi["order"], epi["pool"])  # noqa: E731
+    wino = bool(getattr(step, "wino_fwd", False)) and step.epi is not None
+    if wino:
+        u = ops.wino_mfm_make_u(d, w, epi["ways"])
+        run = lambda: ops.wino_mfm_fwd(d, x, u, b, epi["ways"], epi["order"], epi["pool"])  # noqa: E731
+        kernel = "%s (Winograd F(2x2,3x3), fused epilogue)" % ("wino4_k" if (d.tune_fwd >> 8) & 3 == 2 else "wino_fwd_k")
+    else:
+        run = lambda: ops.conv_mfm_fwd(d, x, w, b, epi["ways"], epi["order"], epi["pool"])  # noqa: E731
+        kernel = "conv_fwd_k<float,1,13,true,1>"
     for _ in range(2):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -72,14 +80,16 @@ def dominant_kernel_roofline(trainer, torch, iters=5):
     flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
     achieved = flops / (ms * 1e-3) / 1e12
     traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))["traffic"]
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), same kernel only
+        prof = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
+        if prof.get("kernel", "conv_fwd_k").split("<")[0].split(" ")[0] == kernel.split("<")[0].split(" ")[0]:
+            traffic = prof["traffic"]
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "conv_fwd_k<1,13,true,1> (conv2 forward 66->198 3x3 @56x56 + bias + MFM3 + pool, B=%d)" % d.batch,
+    return {"bound": "mfma", "kernel": "%s: conv2 forward 66->198 3x3 @56x56 + bias + MFM3 + pool, B=%d" % (kernel, d.batch),
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4), "winograd": wino, "tune_fwd": int(d.tune_fwd)}
 
 
 def cpu_baseline(batch, image, torch):

@@ -41,7 +41,144 @@ struct WinoP {
   int kpad, chunks, nblocks;
   unsigned x_bytes, u_bytes;
   int dbg;
+  // fused bias -> MFM (-> 2x2 max pooling) epilogue (ways > 0): y = z (pooled / MFM output, channel stride cpo), route bytes as
+  // efm_conv_mfm_fwd writes them.  Block nb owns channels [nb*cn, nb*cn + cn) of EVERY slice: column r of its tile = slice r / cnb,
+  // channel nb*cn + r % cnb (wino_u_k permutes the rows of U accordingly).
+  unsigned char* route;
+  int cout, ways, order, pool, cn, cpo;
 };
+
+// ---- final stage of one output column bb (0 / 1) of the 2x2 tiles, shared by both kernel variants.  Rs = [i 0..3][tile 64][RS]
+// holds R_i[bb] = sum_j M[i][j] At[bb][j];  y[a][bb] = sum_i At[a][i] R_i[bb]  (At = [1 1 1 0; 0 1 -1 -1]).
+template <int NB, int NT>
+__device__ __forceinline__ void wino_final(const WinoP& p, const float* Rs, float* state, int bb, int t0, int nb, int tid) {
+  constexpr int RS = NB + 4;
+  const int per = p.th * p.tw;
+  const int n0 = nb * NB;
+  if (p.ways == 0) {
+    constexpr int NQ = NB / 4;
+    for (int it = tid; it < TB * 2 * NQ; it += NT) {
+      const int cq = it % NQ, rest = it / NQ;
+      const int a = rest & 1, tl = rest >> 1;
+      const int tile = t0 + tl, n = n0 + cq * 4;
+      if (tile >= p.tiles || n >= p.cout_p) continue;
+      const int b = tile / per, r = tile - b * per;
+      const int ty = r / p.tw, tx = r - ty * p.tw;
+      const int oy = 2 * ty + a, ox = 2 * tx + bb;
+      if (oy >= p.h || ox >= p.w) continue;
+      const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
+      const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + (2 * TB + tl) * RS + cq * 4);
+      f32x4 v;
+      if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + (0 * TB + tl) * RS + cq * 4) + r1 + r2;
+      else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + (3 * TB + tl) * RS + cq * 4);
+      const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
+      *reinterpret_cast<f32x4*>(p.y + off) = v;
+    }
+    return;
+  }
+  // ---- fused epilogue: thread = (tile, channel j of this block), all slices and both rows a of the column
+  const int ways = p.ways, cs = p.cout / ways;
+  const int cb = nb * p.cn, cnb = min(p.cn, cs - cb);
+  const int co = (ways == 3) ? 2 * cs : cs, cpo = p.cpo;
+  const int hp = p.h >> 1, wp = p.w >> 1;
+  for (int it = tid; it < TB * cnb; it += NT) {
+    const int j = it % cnb, tl = it / cnb;
+    const int tile = t0 + tl;
+    if (tile >= p.tiles) continue;
+    const int b = tile / per, r = tile - b * per;
+    const int ty = r / p.tw, tx = r - ty * p.tw;
+    float ya[2][3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      if (sl < ways) {
+        const int col = sl * cnb + j;
+        const float r0 = Rs[(0 * TB + tl) * RS + col], r1 = Rs[(1 * TB + tl) * RS + col];
+        const float r2 = Rs[(2 * TB + tl) * RS + col], r3 = Rs[(3 * TB + tl) * RS + col];
+        const float bv = p.bias ? p.bias[sl * cs + cb + j] : 0.f;
+        ya[0][sl] = (r0 + r1 + r2) + bv;
+        ya[1][sl] = (r1 - r2 - r3) + bv;
+      } else {
+        ya[0][sl] = ya[1][sl] = 0.f;
+      }
+    }
+    float bmax = 0.f, bmin = 0.f;
+    int rmax = 0, rmin = 0;
+    if (p.pool && bb == 1) {
+      bmax = state[it * 4 + 0]; bmin = state[it * 4 + 1];
+      rmax = __builtin_bit_cast(int, state[it * 4 + 2]); rmin = __builtin_bit_cast(int, state[it * 4 + 3]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float x0 = ya[a][0], x1 = ya[a][1], x2 = ya[a][2];
+      // MXNet tie rules (as conv_fwd_body's fused epilogue): maximum / minimum(lhs, rhs) backward sends a tie to lhs
+      int imax = (x0 >= x1) ? 0 : 1, imin = (x0 <= x1) ? 0 : 1;
+      float vmax = fmaxf(x0, x1), vmin = fminf(x0, x1);
+      if (ways == 3) {
+        if (p.order == EFM_MFM_ORDER_GROUP) {
+          if (!(vmax >= x2)) imax = 2;
+          if (!(vmin <= x2)) imin = 2;
+        } else {
+          if (x2 >= vmax) imax = 2;
+          if (x2 <= vmin) imin = 2;
+        }
+        vmax = fmaxf(vmax, x2);
+        vmin = fminf(vmin, x2);
+      }
+      if (p.pool) {
+        // window scan order is (a, bb) = (0,0) (0,1) (1,0) (1,1) and its FIRST maximum wins; the passes arrive bb-major
+        const int jw = a * 2 + bb;
+        const bool first = (bb == 0 && a == 0);
+        if (first || vmax > bmax || (vmax == bmax && jw * 4 < (rmax & ~3))) { bmax = vmax; rmax = jw * 4 + imax; }
+        if (first || vmin > bmin || (vmin == bmin && jw * 4 < (rmin & ~3))) { bmin = vmin; rmin = jw * 4 + imin; }
+      } else {
+        const int oy = 2 * ty + a, ox = 2 * tx + bb;
+        if (oy < p.h && ox < p.w) {
+          const long m = (long)(b * p.h + oy) * p.w + ox;
+          p.y[m * cpo + cb + j] = vmax;
+          p.route[m * cpo + cb + j] = (unsigned char)imax;
+          if (ways == 3) {
+            p.y[m * cpo + cs + cb + j] = vmin;
+            p.route[m * cpo + cs + cb + j] = (unsigned char)imin;
+          }
+        }
+      }
+    }
+    if (p.pool) {
+      if (bb == 0) {
+        state[it * 4 + 0] = bmax; state[it * 4 + 1] = bmin;
+        state[it * 4 + 2] = __builtin_bit_cast(float, rmax); state[it * 4 + 3] = __builtin_bit_cast(float, rmin);
+      } else if (ty < hp && tx < wp) {
+        const long q = (long)(b * hp + ty) * wp + tx;
+        p.y[q * cpo + cb + j] = bmax;
+        p.route[q * cpo + cb + j] = (unsigned char)rmax;
+        if (ways == 3) {
+          p.y[q * cpo + cs + cb + j] = bmin;
+          p.route[q * cpo + cs + cb + j] = (unsigned char)rmin;
+        }
+      }
+    }
+  }
+  // pad channels of z (written once, by channel block 0)
+  if (nb == 0 && cpo > co) {
+    const int npad = cpo - co;
+    for (int it = tid; it < TB * 2 * npad; it += NT) {
+      const int pc = it % npad, rest = it / npad;
+      const int a = rest & 1, tl = rest >> 1;
+      const int tile = t0 + tl;
+      if (tile >= p.tiles) continue;
+      const int b = tile / per, r = tile - b * per;
+      const int ty = r / p.tw, tx = r - ty * p.tw;
+      if (p.pool) {
+        if (bb == 1 && a == 0 && ty < hp && tx < wp) p.y[((long)(b * hp + ty) * wp + tx) * cpo + co + pc] = 0.f;
+      } else {
+        const int oy = 2 * ty + a, ox = 2 * tx + bb;
+        if (oy < p.h && ox < p.w) p.y[((long)(b * p.h + oy) * p.w + ox) * cpo + co + pc] = 0.f;
+      }
+    }
+  }
+}
 
 template <int CTRL>
 __device__ __forceinline__ float quad(float v) {
@@ -61,7 +198,12 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wh = wave & 1;
   const int fi = lane & 15, fq = lane >> 4;
-  const int nb = (int)blockIdx.x % p.nblocks, tb = (int)blockIdx.x / p.nblocks;
+  // XCD-aware bijective remap (workgroups go round-robin over the 8 XCDs, each with its own L2): consecutive logical blocks — the
+  // channel blocks of one tile group, which read the same x patches and write the same output lines — share one XCD
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nb = lid % p.nblocks, tb = lid / p.nblocks;
   const int t0 = tb * TB, n0 = nb * NB;
   const int per = p.th * p.tw;
 
@@ -171,7 +313,6 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
   // ---- epilogue.  In registers: R_i[b] = sum_j M[i][j] * At[b][j]  (At = [1 1 1 0; 0 1 -1 -1]); through LDS, one output column b
   // per pass: y[a][b] = sum_i At[a][i] R_i[b]
   float* Rs = smem;  // [i][tile 64][RS]
-  constexpr int NQ = NB / 4;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
 #pragma unroll
@@ -187,25 +328,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
       }
     }
     __syncthreads();
-    for (int it = tid; it < TB * 2 * NQ; it += 512) {
-      const int cq = it % NQ, rest = it / NQ;
-      const int a = rest & 1, tl = rest >> 1;
-      const int tile = t0 + tl, n = n0 + cq * 4;
-      if (tile >= p.tiles || n >= p.cout_p) continue;
-      const int b = tile / per, r = tile - b * per;
-      const int ty = r / p.tw, tx = r - ty * p.tw;
-      const int oy = 2 * ty + a, ox = 2 * tx + bb;
-      if (oy >= p.h || ox >= p.w) continue;
-      const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
-      const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + (2 * TB + tl) * RS + cq * 4);
-      f32x4 v;
-      if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + (0 * TB + tl) * RS + cq * 4) + r1 + r2;
-      else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + (3 * TB + tl) * RS + cq * 4);
-      const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
-      *reinterpret_cast<f32x4*>(p.y + off) = v;
-    }
+    wino_final<NB, 512>(p, Rs, smem + 4 * TB * RS, bb, t0, nb, tid);
     if (bb == 0) __syncthreads();
   }
 }
@@ -213,7 +336,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
 template <int NTB>
 __global__ void __launch_bounds__(512, 1) wino_fwd_k(const WinoP p) {
   constexpr int STAGE = V_STAGE + 16 * 16 * NTB * KC;
-  constexpr int EPI = 4 * TB * (16 * NTB + 4);
+  constexpr int EPI = 4 * TB * (16 * NTB + 4) + TB * (8 * NTB) * 4;  // R exchange + the pooled epilogue's per-item state
   __shared__ __attribute__((aligned(16))) float smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
   wino_body<NTB>(p, smem);
 }
@@ -231,7 +354,12 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
   constexpr int RS = NB + 4;
   const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
   const int fi = lane & 15, fq = lane >> 4;
-  const int nb = (int)blockIdx.x % p.nblocks, tb = (int)blockIdx.x / p.nblocks;
+  // XCD-aware bijective remap (workgroups go round-robin over the 8 XCDs, each with its own L2): consecutive logical blocks — the
+  // channel blocks of one tile group, which read the same x patches and write the same output lines — share one XCD
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nb = lid % p.nblocks, tb = lid / p.nblocks;
   const int t0 = tb * TB, n0 = nb * NB;
   const int per = p.th * p.tw;
 
@@ -331,7 +459,6 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
   }
 
   float* Rs = smem;  // [i][tile 64][RS]
-  constexpr int NQ = NB / 4;
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb) {
 #pragma unroll
@@ -346,25 +473,7 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
       }
     }
     __syncthreads();
-    for (int it = tid; it < TB * 2 * NQ; it += 256) {
-      const int cq = it % NQ, rest = it / NQ;
-      const int a = rest & 1, tl = rest >> 1;
-      const int tile = t0 + tl, n = n0 + cq * 4;
-      if (tile >= p.tiles || n >= p.cout_p) continue;
-      const int b = tile / per, r = tile - b * per;
-      const int ty = r / p.tw, tx = r - ty * p.tw;
-      const int oy = 2 * ty + a, ox = 2 * tx + bb;
-      if (oy >= p.h || ox >= p.w) continue;
-      const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
-      const f32x4 r2 = *reinterpret_cast<const f32x4*>(Rs + (2 * TB + tl) * RS + cq * 4);
-      f32x4 v;
-      if (a == 0) v = *reinterpret_cast<const f32x4*>(Rs + (0 * TB + tl) * RS + cq * 4) + r1 + r2;
-      else v = r1 - r2 - *reinterpret_cast<const f32x4*>(Rs + (3 * TB + tl) * RS + cq * 4);
-      const long off = ((long)(b * p.h + oy) * p.w + ox) * p.cout_p + n;
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + off);
-      *reinterpret_cast<f32x4*>(p.y + off) = v;
-    }
+    wino_final<NB, 256>(p, Rs, smem + 4 * TB * RS, bb, t0, nb, tid);
     if (bb == 0) __syncthreads();
   }
 }
@@ -372,7 +481,7 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
 template <int NTB>
 __global__ void __launch_bounds__(256, 2) wino4_k(const WinoP p) {
   constexpr int STAGE = V4_STAGE + 16 * 16 * NTB * KC4;
-  constexpr int EPI = 4 * TB * (16 * NTB + 4);
+  constexpr int EPI = 4 * TB * (16 * NTB + 4) + TB * (8 * NTB) * 4;
   __shared__ __attribute__((aligned(16))) float smem[(2 * STAGE > EPI) ? 2 * STAGE : EPI];
   wino4_body<NTB>(p, smem);
 }
@@ -381,11 +490,20 @@ __global__ void __launch_bounds__(256, 2) wino4_k(const WinoP p) {
 // forward:       row n = output channel, k = input channel,  g[p][q] = w[n][(p*3 + q)*cin_p + k]
 // data gradient: row n = input channel,  k = output channel, g[p][q] = w[k][((2-p)*3 + (2-q))*cin_p + n]   (tap-flipped transpose)
 // both read the packed forward weights w[n_pad16][k_pad].  One thread per (n, k).
+// fused-epilogue forward (ways > 0): row r of channel block blk is output channel slice*cs + blk*cn + r % cnb, slice = r / cnb
+// (every slice of a channel in one block), rows past the last slice are zero.
 __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin, int k_pad_src,
-                                                int cin_p, int n_rows, int nbr, int kpad) {
+                                                int cin_p, int n_rows, int nbr, int kpad, int ways, int cn) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)n_rows * kpad) return;
-  const int n = (int)(i / kpad), k = (int)(i - (long)n * kpad);
+  const int nrow = (int)(i / kpad), k = (int)(i - (long)nrow * kpad);
+  int n = nrow;
+  if (ways > 0) {
+    const int blk0 = nrow / nbr, r = nrow - blk0 * nbr;
+    const int cs = cout / ways, cb = blk0 * cn, cnb = min(cn, cs - cb);
+    const int sl = (cnb > 0) ? r / cnb : ways;
+    n = (sl < ways) ? sl * cs + cb + (r - sl * cnb) : cout;  // cout = out of range -> zero row
+  }
   const bool ok = dgrad ? (n < cin && k < cout) : (n < cout && k < cin);
   float g[3][3];
 #pragma unroll
@@ -404,7 +522,7 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
-  const int blk = n / nbr, row = n - blk * nbr;
+  const int blk = nrow / nbr, row = nrow - blk * nbr;
   float* dst = u + ((long)blk * 16 * nbr + row) * kpad + k;
   const long plane = (long)nbr * kpad;
 #pragma unroll
@@ -418,6 +536,7 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
 
 struct WinoPlan {
   int NTB, nblocks, n_rows, kpad, variant;
+  int cn;  // fused epilogue: channels of every slice per block
 };
 
 // bits 9:8 of a descriptor's tune field pick the kernel variant: 0 = default (EFM_WINO_VARIANT, else the 4-wave kernel),
@@ -430,10 +549,23 @@ int wino_variant(int tune) {
 
 // output-channel tiles per block: as few blocks as possible with at most EFM_WINO_NTB (default 5) tiles each
 // (two stages of V 32 KB + U 8*NTB KB must fit the 160 KB of LDS, 32*NTB accumulator registers the 256 per lane)
-WinoPlan plan_wino(int cin_p, int cout, int tune) {
+WinoPlan plan_wino(int cin_p, int cout, int tune, int ways = 0) {
   WinoPlan pl;
   const int tiles = (cout + 15) / 16;
   pl.variant = wino_variant(tune);
+  pl.cn = 0;
+  if (ways > 0) {  // fused epilogue: a block holds `ways` slices of cn channels; as few blocks as the widest tile allows
+    static const int max8 = [] { const char* e = getenv("EFM_WINO_NTB"); return e ? atoi(e) : 5; }();
+    const int maxnb = (pl.variant == 4) ? 48 : 16 * max8;
+    const int cs = cout / ways;
+    pl.nblocks = (cs + maxnb / ways - 1) / (maxnb / ways);
+    pl.cn = (cs + pl.nblocks - 1) / pl.nblocks;
+    pl.nblocks = (cs + pl.cn - 1) / pl.cn;
+    pl.NTB = std::max(pl.variant == 4 ? 2 : 3, (ways * pl.cn + 15) / 16);
+    pl.n_rows = pl.nblocks * pl.NTB * 16;
+    pl.kpad = (pl.variant == 4) ? cin_p : (cin_p + KC - 1) / KC * KC;
+    return pl;
+  }
   if (pl.variant == 4) {  // 4-wave blocks: 2 or 3 channel tiles per block, whichever pads less (3 on a tie)
     const int b3 = (tiles + 2) / 3, b2 = (tiles + 1) / 2;
     pl.NTB = (3 * b3 <= 2 * b2) ? 3 : 2;
@@ -451,9 +583,11 @@ WinoPlan plan_wino(int cin_p, int cout, int tune) {
 }
 
 int run_wino(const float* x, const float* u, const float* bias, const float* res, float* y, int batch, int h, int w, int cin_p, int cout,
-             int cout_p, int tune, hipStream_t s) {
-  const WinoPlan pl = plan_wino(cin_p, cout, tune);
+             int cout_p, int tune, hipStream_t s, unsigned char* route = nullptr, int ways = 0, int order = 0, int pool = 0) {
+  const WinoPlan pl = plan_wino(cin_p, cout, tune, ways);
   WinoP p;
+  p.route = route; p.cout = cout; p.ways = ways; p.order = order; p.pool = pool; p.cn = pl.cn;
+  p.cpo = ways ? efm_pad4(ways == 3 ? 2 * (cout / 3) : cout / 2) : 0;
   p.x = x; p.u = u; p.bias = bias; p.res = res; p.y = y;
   p.batch = batch; p.h = h; p.w = w; p.cin_p = cin_p; p.cout_p = cout_p;
   p.th = (h + 1) / 2; p.tw = (w + 1) / 2; p.tiles = batch * p.th * p.tw;
@@ -499,8 +633,34 @@ int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int
   const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd);
   const long total = (long)pl.n_rows * pl.kpad;
   hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, dgrad ? 1 : 0, d->cout,
-                     d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad);
+                     d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, 0, 0);
   return efm::check_launch("wino_make_u");
+}
+
+size_t efm_wino_mfm_u_elems(const efm_conv_desc* d, int ways) {
+  if (!d || (ways != 2 && ways != 3) || d->cout % ways) return 0;
+  const WinoPlan pl = plan_wino(d->cin_p, d->cout, d->tune_fwd, ways);
+  return (size_t)16 * pl.n_rows * pl.kpad;
+}
+
+int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int ways, void* stream) {
+  EFM_REQUIRE(efm_wino_supported(d) && w_packed && u, "wino_mfm_make_u: unsupported descriptor or null argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "wino_mfm_make_u: cout=%d not divisible by ways=%d", d->cout, ways);
+  const WinoPlan pl = plan_wino(d->cin_p, d->cout, d->tune_fwd, ways);
+  const long total = (long)pl.n_rows * pl.kpad;
+  hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, 0, d->cout, d->cin,
+                     d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, ways, pl.cn);
+  return efm::check_launch("wino_mfm_make_u");
+}
+
+int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z, unsigned char* route, int ways,
+                     int order, int pool, void* stream) {
+  EFM_REQUIRE(efm_wino_supported(d) && x && u && z && route, "wino_mfm_fwd: unsupported descriptor or null argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "wino_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "wino_mfm_fwd: bad order %d", order);
+  EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "wino_mfm_fwd: pooling needs a map of at least 2x2");
+  return run_wino(x, u, bias, nullptr, z, d->batch, d->hin, d->win, d->cin_p, d->cout, d->cout_p, d->tune_fwd, (hipStream_t)stream, route,
+                  ways, order, pool ? 1 : 0);
 }
 
 int efm_wino_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, const float* residual, float* y, void* stream) {

@@ -464,3 +464,24 @@ def wino_bwd_data(d, dy, u_dgrad, add=None, out=None):
     dx = out if out is not None else torch.empty((d.batch, d.hin, d.win, d.cin_p), dtype=torch.float32, device=dy.device)
     check(_lib.load().efm_wino_bwd_data(ctypes.byref(d), _p(dy), _p(u_dgrad), _p(add), _p(dx), _stream()), "efm_wino_bwd_data")
     return dx
+
+
+def wino_mfm_make_u(d, w, ways, out=None):
+    _need_dev(w)
+    n = _lib.load().efm_wino_mfm_u_elems(ctypes.byref(d), ways)
+    u = out if out is not None else torch.empty((n,), dtype=torch.float32, device=w.device)
+    check(_lib.load().efm_wino_mfm_make_u(ctypes.byref(d), _p(w), _p(u), ways, _stream()), "efm_wino_mfm_make_u")
+    return u
+
+
+def wino_mfm_fwd(d, x, u, bias, ways=3, order=_lib.MFM_ORDER_GROUP, pool=False):
+    """Winograd form of conv_mfm_fwd: -> (z, route) in the same layout."""
+    _need_dev(x, u)
+    cs = d.cout // ways
+    co = 2 * cs if ways == 3 else cs
+    h, w = (d.hout // 2, d.wout // 2) if pool else (d.hout, d.wout)
+    z = torch.empty((d.batch, h, w, pad4(co)), dtype=torch.float32, device=x.device)
+    route = torch.empty((d.batch, h, w, pad4(co)), dtype=torch.uint8, device=x.device)
+    check(_lib.load().efm_wino_mfm_fwd(ctypes.byref(d), _p(x), _p(u), _p(bias), _p(z), _p(route), ways, order, 1 if pool else 0, _stream()),
+          "efm_wino_mfm_fwd")
+    return z, route

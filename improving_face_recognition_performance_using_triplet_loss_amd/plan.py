@@ -324,8 +324,14 @@ class Plan:
                 w = v[st.pname + "_weight"]
                 bias = None if st.no_bias else v[st.pname + "_bias"]
                 if st.epi is not None:
-                    acts[st.index], aux[st.index] = ops.conv_mfm_fwd(st.desc, acts[st.inputs[0].index], w, bias, st.epi["ways"],
-                                                                     st.epi["order"], st.epi["pool"])
+                    e = st.epi
+                    if getattr(st, "wino_fwd", False):
+                        st.u_fwd = ops.wino_mfm_make_u(st.desc, w, e["ways"], out=getattr(st, "u_fwd", None))
+                        acts[st.index], aux[st.index] = ops.wino_mfm_fwd(st.desc, acts[st.inputs[0].index], st.u_fwd, bias, e["ways"],
+                                                                         e["order"], e["pool"])
+                    else:
+                        acts[st.index], aux[st.index] = ops.conv_mfm_fwd(st.desc, acts[st.inputs[0].index], w, bias, e["ways"],
+                                                                         e["order"], e["pool"])
                     continue
                 res = acts[st.residual.index] if st.residual is not None else None
                 if getattr(st, "wino_fwd", False):  # Winograd F(2x2,3x3): chosen by autotune() where it is faster
@@ -530,8 +536,22 @@ class Plan:
             else:  # fused epilogue: number of channel blocks
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 e = st.epi
-                chosen[st.pname + ":fused"] = best(lambda: ops.conv_mfm_fwd(d, x, w, None, e["ways"], e["order"], e["pool"]), d,
-                                                   "tune_fwd", [0, 1 << 4, 2 << 4, 3 << 4])[0]
+                win, times = best(lambda: ops.conv_mfm_fwd(d, x, w, None, e["ways"], e["order"], e["pool"]), d,
+                                  "tune_fwd", [0, 1 << 4, 2 << 4, 3 << 4])
+                chosen[st.pname + ":fused"] = win
+                if wino and ops.wino_supported(d):
+                    tw = {}
+                    for var in (1, 2):
+                        d.tune_fwd = var << 8
+                        u = ops.wino_mfm_make_u(d, w, e["ways"])
+                        tw[var] = timed(lambda: ops.wino_mfm_fwd(d, x, u, None, e["ways"], e["order"], e["pool"]))
+                    var = min(tw, key=tw.get)
+                    if tw[var] < 0.97 * times[win] or force:
+                        st.wino_fwd = True
+                        d.tune_fwd = var << 8
+                        chosen[st.pname + ":fused"] = "winograd/%d" % (8 if var == 1 else 4)
+                    else:
+                        d.tune_fwd = win
             if st.inputs[0].needs_grad:
                 wd = torch.rand((d.dn_pad16, d.dk_pad), device=self.device)
                 dx = torch.empty_like(x)

@@ -188,6 +188,13 @@ int efm_wino_fwd(const efm_conv_desc* d, const float* x, const float* u, const f
                  float* y, void* stream);
 int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dgrad, const float* add, float* dx,
                       void* stream);
+/* Winograd forward with the fused bias -> MFM (-> 2x2 max pooling) epilogue: same z / route outputs and tie rules as
+ * efm_conv_mfm_fwd (so efm_mfm_pool_bwd is its backward), U made by efm_wino_mfm_make_u (rows grouped so that every slice of a
+ * channel meets in one block). */
+size_t efm_wino_mfm_u_elems(const efm_conv_desc* d, int ways);
+int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int ways, void* stream);
+int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z,
+                     unsigned char* route, int ways, int order, int pool, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Embedding head / loss (dense row-major matrices, leading dimension = ld* floats).

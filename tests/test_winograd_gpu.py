@@ -87,3 +87,63 @@ def test_plan_with_winograd_layers_matches_direct_plan(monkeypatch):
     # implementations differ by ~6e-3 there (measured in test_e2e_gpu.py::test_112_step_vs_oracles); a wiring error would be O(1).
     # The kernels themselves are compared tightly above.
     assert rel_err(out["winograd"][2].cpu().numpy(), out["direct"][2].cpu().numpy()) < 3e-2
+
+
+# (batch, h, w, cin, cout, ways, pool): MFM3 / MFM2, pooled (a 2x2 tile is the pooling window; 7 -> 3 floor pooling drops the half tile)
+# and unpooled, one and several channel blocks, tile counts off the 64-tile grid
+FUSED = [(2, 8, 8, 8, 18, 3, True), (3, 14, 14, 44, 99, 3, False), (2, 7, 7, 58, 261, 3, True), (1, 28, 28, 24, 198, 3, True),
+         (2, 6, 10, 5, 34, 2, True), (3, 7, 5, 20, 96, 2, False), (1, 14, 14, 40, 387, 3, False), (2, 16, 16, 16, 256, 2, True)]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("case", FUSED)
+def test_wino_fused_epilogue(case, variant):
+    """efm_wino_mfm_fwd = efm_wino_fwd followed by the stand-alone MFM / pooling kernels, BITWISE (same arithmetic, same tie rules),
+    and its route bytes drive efm_mfm_pool_bwd to the same gradient as the unfused backward chain."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w, cin, cout, ways, pool = case
+    x = rand((b, cin, h, w), 31)
+    wt = rand((cout, cin, 3, 3), 32, 0.2)
+    bias = rand((cout,), 33)
+    d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+    d.tune_fwd = variant << 8   # 1 = 8-wave kernel, 2 = 4-wave kernel
+    xd = to_nhwc(x)
+    wp = ops.conv_pack_weights(d, dev(wt))
+    bp = torch.zeros(d.n_pad16, device="cuda")
+    bp[:cout] = dev(bias)
+    y_ref = O.conv2d(x, wt, bias, (1, 1))
+    z_ref = O.mfm3(y_ref) if ways == 3 else O.mfm2(y_ref)
+    if pool:
+        z_ref = O.maxpool2(z_ref)
+    co = z_ref.shape[1]
+    y = ops.wino_fwd(d, xd, ops.wino_make_u(d, wp), bp)
+    for order in (O.ORDER_GROUP, O.ORDER_RES):
+        z, route = ops.wino_mfm_fwd(d, xd, ops.wino_mfm_make_u(d, wp, ways), bp, ways, order, pool)
+        assert rel_err(from_nhwc(z, co), z_ref) < TOL
+        mf = ops.mfm_fwd(y, cout, ways)
+        zu = ops.maxpool2_fwd(mf, co) if pool else mf
+        assert torch.equal(z, zu)
+        dzd = to_nhwc(rand(z_ref.shape, 34))
+        dyf = ops.mfm_pool_bwd(d, route, dzd, ways, pool)
+        dmf = ops.maxpool2_bwd(mf, dzd, co) if pool else dzd
+        assert torch.equal(dyf, ops.mfm_bwd(y, dmf, cout, ways, order))
+
+
+def test_wino_fused_pool_ties_pick_first_maximum():
+    """Constant input and weights: all four pixels of interior windows tie, and the slices tie too — the route must be the FIRST
+    window pixel and the lhs slice, as the direct kernel and MXNet's pooling / maximum backward choose."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w, cin, cout = 1, 8, 8, 4, 48
+    d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+    xd = torch.ones((b, h, w, d.cin_p), device="cuda")
+    wt = np.zeros((cout, cin, 3, 3))
+    wt[:, :, 1, 1] = 0.25          # centre tap only: every output pixel = 1.0 exactly, whatever the border
+    wp = ops.conv_pack_weights(d, dev(wt))
+    bp = torch.zeros(d.n_pad16, device="cuda")
+    for variant in (1, 2):
+        d.tune_fwd = variant << 8
+        u = ops.wino_mfm_make_u(d, wp, 3)
+        for order in (O.ORDER_GROUP, O.ORDER_RES):
+            z, route = ops.wino_mfm_fwd(d, xd, u, bp, 3, order, True)
+            zd, rd = ops.conv_mfm_fwd(ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1), xd, wp, bp, 3, order, True)
+            assert torch.equal(z, zd) and torch.equal(route, rd)
