@@ -62,6 +62,8 @@ SIGNATURES = {
     "efm_wino_make_u": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]),
     "efm_wino_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 6),
     "efm_wino_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
+    "efm_wino_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "efm_wino_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "efm_wino_mfm_u_elems": (c_size_t, [POINTER(ConvDesc), c_int]),
     "efm_wino_mfm_make_u": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]),
     "efm_wino_mfm_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),

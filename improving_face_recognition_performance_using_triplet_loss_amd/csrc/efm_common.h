@@ -31,6 +31,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Shared by the direct and the Winograd weight-gradient paths (defined in efm_conv.hip).
+// reduce_slabs: out[i] (+)= sum over `count` slabs of n4 float4 each, fixed order (two levels above 32 slabs; tmp holds ceil(count/32) slabs).
+int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s);
+// bias_grad: dbias[n_pad16] (+)= column sums of dy (M x cout_p); ws holds bias_grad_ws_floats(d) floats.
+size_t bias_grad_ws_floats(const efm_conv_desc* d);
+int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s);
+
 }  // namespace efm
 
 #define EFM_REQUIRE(cond, ...)        \

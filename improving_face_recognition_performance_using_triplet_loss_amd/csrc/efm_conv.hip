@@ -20,6 +20,7 @@
 //   The weight gradient contracts over pixels: C[n][k] = sum_m dy[m][n] * A[m][k], split over
 //   m into workspace slabs and reduced in a fixed order (bitwise reproducible).
 #include <algorithm>
+#include <string.h>
 
 #include "efm_common.h"
 
@@ -1161,6 +1162,42 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
 }
 
 }  // namespace
+
+namespace efm {
+
+int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s) {
+  const unsigned gx = (unsigned)efm::cdiv(n4, 64);
+  if (count > 32) {
+    const int groups = (count + 31) / 32;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, in, tmp, n4, n4, count, 32, n4, 0);
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, groups, groups, n4, accumulate);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, count, count, n4, accumulate);
+  }
+  return efm::check_launch("slab_reduce");
+}
+
+size_t bias_grad_ws_floats(const efm_conv_desc* d) {
+  const int chunks = (d->batch * d->hout * d->wout + BIAS_ROWS - 1) / BIAS_ROWS;
+  return (size_t)(chunks + (chunks + 31) / 32) * d->n_pad16;
+}
+
+int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s) {
+  WgradP p;
+  memset(&p, 0, sizeof(p));
+  p.dy = dy;
+  p.M = d->batch * d->hout * d->wout;
+  p.cout_p = d->cout_p; p.n_pad16 = d->n_pad16;
+  const int chunks = (p.M + BIAS_ROWS - 1) / BIAS_ROWS;
+  p.bias_part = ws;
+  p.mma_blocks = 0;  // every block of the launch is a column-sum block
+  hipLaunchKernelGGL((conv_wgrad_k<1, 3>), dim3((unsigned)chunks), dim3(256), 0, s, p);
+  int rc = efm::check_launch("bias_grad");
+  if (rc != EFM_OK) return rc;
+  return reduce_slabs(ws, ws + (size_t)chunks * d->n_pad16, dbias, d->n_pad16 / 4, chunks, accumulate, s);
+}
+
+}  // namespace efm
 
 extern "C" {
 

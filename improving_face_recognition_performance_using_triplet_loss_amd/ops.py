@@ -485,3 +485,18 @@ def wino_mfm_fwd(d, x, u, bias, ways=3, order=_lib.MFM_ORDER_GROUP, pool=False):
     check(_lib.load().efm_wino_mfm_fwd(ctypes.byref(d), _p(x), _p(u), _p(bias), _p(z), _p(route), ways, order, 1 if pool else 0, _stream()),
           "efm_wino_mfm_fwd")
     return z, route
+
+
+def wino_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=False):
+    """Winograd form of conv_bwd_weight (3x3 / pad 1): same outputs and workspace handling."""
+    _need_dev(x, dy, dw, dbias)
+    if dw is None:
+        dw = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((d.n_pad16,), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.efm_wino_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = workspace(nbytes, x.device)
+    check(lib.efm_wino_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), int(bool(accumulate)), _p(ws),
+                                  ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_wino_bwd_weight")
+    return dw, (dbias if want_bias else None)

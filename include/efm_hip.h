@@ -191,6 +191,10 @@ int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dg
 /* Winograd forward with the fused bias -> MFM (-> 2x2 max pooling) epilogue: same z / route outputs and tie rules as
  * efm_conv_mfm_fwd (so efm_mfm_pool_bwd is its backward), U made by efm_wino_mfm_make_u (rows grouped so that every slice of a
  * channel meets in one block). */
+/* Weight gradient in Winograd form (same outputs, workspace protocol and determinism as efm_conv_bwd_weight). */
+size_t efm_wino_wgrad_workspace_bytes(const efm_conv_desc* d);
+int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t efm_wino_mfm_u_elems(const efm_conv_desc* d, int ways);
 int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int ways, void* stream);
 int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z,

@@ -147,3 +147,30 @@ def test_wino_fused_pool_ties_pick_first_maximum():
             z, route = ops.wino_mfm_fwd(d, xd, u, bp, 3, order, True)
             zd, rd = ops.conv_mfm_fwd(ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1), xd, wp, bp, 3, order, True)
             assert torch.equal(z, zd) and torch.equal(route, rd)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_wgrad(case):
+    """Winograd weight gradient (+ bias gradient) against the fp64 oracle and the direct kernel; accumulate mode; the packed
+    gradient's pads are exact zeros; bitwise reproducible."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w, cin, cout = case
+    x = rand((b, cin, h, w), 1)
+    wt = rand((cout, cin, 3, 3), 2, 0.2)
+    dy = rand((b, cout, h, w), 5)
+    d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+    xd, dyd = to_nhwc(x), to_nhwc(dy)
+    _, dw_ref, db_ref = O.conv2d_bwd(x, wt, dy, (1, 1))
+    dw, db = ops.wino_bwd_weight(d, xd, dyd)
+    assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < TOL
+    assert rel_err(db[:cout].cpu().numpy(), db_ref) < TOL
+    dwd, dbd = ops.conv_bwd_weight(d, xd, dyd)
+    assert rel_err(dw.cpu().numpy(), dwd.cpu().numpy()) < 1e-5 and rel_err(db.cpu().numpy(), dbd.cpu().numpy()) < 1e-5
+    dwm = dw.clone()
+    ops.conv_pack_weights_into(d, ops.conv_unpack_weights(d, dw), dwm)
+    assert torch.equal(dwm, dw)                       # pad rows / columns are exactly zero
+    dw2, db2 = ops.wino_bwd_weight(d, xd, dyd)
+    assert torch.equal(dw2, dw) and torch.equal(db2, db)
+    acc_w, acc_b = dw.clone(), db.clone()
+    ops.wino_bwd_weight(d, xd, dyd, dw=acc_w, dbias=acc_b, accumulate=True)
+    assert rel_err(acc_w.cpu().numpy(), 2 * dw.cpu().numpy()) < 1e-6 and rel_err(acc_b.cpu().numpy(), 2 * db.cpu().numpy()) < 1e-6

@@ -86,10 +86,12 @@ def main():
                     ms = timeit(lambda: ops.convb_bwd_data(d, dyb, wdb), a.iters)
                 else:
                     ms = timeit(lambda: ops.convb_bwd_weight(d, xb, dyb, dw=dw, dbias=db), a.iters)
-            elif k in ("wfwd", "wdgrad"):
+            elif k in ("wfwd", "wdgrad", "wwgrad"):
                 if not ops.wino_supported(d):
                     continue
-                if k == "wfwd":
+                if k == "wwgrad":
+                    ms = timeit(lambda: ops.wino_bwd_weight(d, x, dy, dw=dw, dbias=db), a.iters)
+                elif k == "wfwd":
                     u = ops.wino_make_u(d, w)
                     ms = timeit(lambda: ops.wino_fwd(d, x, u, b, out=y), a.iters)
                 else:
