@@ -558,6 +558,7 @@ struct WinoWP {
   int n_pad16, k_pad;
   int cob, cib, splits, tps;  // channel blocks, tile splits, tiles per split (multiple of 4)
   unsigned x_bytes, y_bytes;
+  int dbg;
 };
 
 __device__ __forceinline__ int fdivw(int m, int d, float inv) {
@@ -686,16 +687,17 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_k(const WinoWP p) {
     }
   };
 
+  const bool dl_ = !(p.dbg & 1), dt_ = !(p.dbg & 2), dc_ = !(p.dbg & 4);
   if (chunks > 0) {
-    load(0);
-    transform(0);
-    if (chunks > 1) load(1);
+    if (dl_) load(0);
+    if (dt_) transform(0);
+    if (chunks > 1 && dl_) load(1);
   }
   __syncthreads();
   for (int ch = 0; ch < chunks; ++ch) {
-    if (ch + 1 < chunks) transform((ch + 1) & 1);
-    if (ch + 2 < chunks) load(ch + 2);
-    compute(ch & 1);
+    if (ch + 1 < chunks && dt_) transform((ch + 1) & 1);
+    if (ch + 2 < chunks && dl_) load(ch + 2);
+    if (dc_) compute(ch & 1);
     __syncthreads();
   }
 
@@ -923,6 +925,7 @@ int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   p.cob = pl.cob; p.cib = pl.cib; p.splits = pl.splits; p.tps = pl.tps;
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * 4);
   p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * d->cout_p * 4);
+  { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
   hipLaunchKernelGGL(wino_wgrad_k, dim3((unsigned)(pl.cob * pl.cib * pl.splits)), dim3(256), 0, s, p);
   int rc = efm::check_launch("wino_wgrad");
   if (rc != EFM_OK) return rc;
