@@ -492,7 +492,14 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   constexpr int TILE = BP * (BKR + BNW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware bijective remap over the matrix-core blocks (workgroups go round-robin over the 8 XCDs, each with its own L2): the
+  // kblocks*nblocks tiles of one pixel split read the same x / dy rows, so consecutive logical blocks share one XCD
   int bid = blockIdx.x;
+  {
+    const int nwg = p.mma_blocks;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
   const int tiles = p.kblocks * p.nblocks;
   const int split = bid / tiles;
   bid -= split * tiles;
@@ -960,7 +967,14 @@ __device__ __forceinline__ void convb_wgrad_body(const WgradBP& p, __bf16* smem)
   constexpr int PX = (BP * K8 + 255) / 256, PY = (BP * N8 + 255) / 256;
   constexpr int TILE = BP * (BKR + BNW);              // bf16 elements per stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware bijective remap over the matrix-core blocks (workgroups go round-robin over the 8 XCDs, each with its own L2): the
+  // kblocks*nblocks tiles of one pixel split read the same x / dy rows, so consecutive logical blocks share one XCD
   int bid = blockIdx.x;
+  {
+    const int nwg = p.mma_blocks;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  }
   const int tiles = p.kblocks * p.nblocks;
   const int split = bid / tiles;
   bid -= split * tiles;
@@ -1300,8 +1314,10 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.magic_kw = (unsigned)((0x100000000ULL + (unsigned)d->kw - 1) / (unsigned)d->kw);
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
-  dim3 grid((unsigned)(efm::cdiv(p.M, 64) * nsplit));
-  int rc = launch_fwd_epi<float, 1>(NT, grid, (hipStream_t)stream, p);
+  // 128-row tiles (tune_fwd & 15 == 2) halve the weight-tile traffic per pixel: pays for the short-K layers (conv1, the 1x1s)
+  const int MT = mt_fit(((d->tune_fwd & 15) == 2) ? env_int("EFM_EPI_MT", 2) : env_int("EFM_EPI_MT", 1), NT);
+  dim3 grid((unsigned)(efm::cdiv(p.M, 64 * MT) * nsplit));
+  int rc = (MT == 2) ? launch_fwd_epi<float, 2>(NT, grid, (hipStream_t)stream, p) : launch_fwd_epi<float, 1>(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
   return efm::check_launch("conv_mfm_fwd");
 }

@@ -537,7 +537,7 @@ class Plan:
                 w = torch.rand((d.n_pad16, d.k_pad), device=self.device)
                 e = st.epi
                 win, times = best(lambda: ops.conv_mfm_fwd(d, x, w, None, e["ways"], e["order"], e["pool"]), d,
-                                  "tune_fwd", [0, 1 << 4, 2 << 4, 3 << 4])
+                                  "tune_fwd", [0, 1 << 4, 2 << 4, 3 << 4, 2, 2 | (1 << 4), 2 | (2 << 4)])
                 chosen[st.pname + ":fused"] = win
                 if wino and ops.wino_supported(d):
                     tw = {}
