@@ -171,7 +171,7 @@ def main():
         flop_per_image = 3 * 5199839232 - 180633600 if deep else 4667572224
         tr = MiningTripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
                                   outputs=efm_symbol.deepcnn_embedding_net() if deep else efm_symbol.lightcnn9_embedding_net(),
-                                  dtype=args.dtype)
+                                  dtype=args.dtype, autotune=args.dtype == "f32" and os.environ.get("EFM_AUTOTUNE", "1") != "0")
         ids = (torch.arange(args.batch) // 4) + rank * (args.batch // 4)  # P = B/4 identities x K = 4 images
         tr.set_labels(ids)
         batches = [(synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device), None) for s in range(2)]
