@@ -71,6 +71,8 @@ SIGNATURES = {
     "efm_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_mfm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "efm_mfm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "efm_mfmb_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "efm_mfmb_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "efm_maxpool2_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_maxpool2_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_l2norm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -42,50 +42,50 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_k(const float* __restrict__ 
 // ---- MFM -----------------------------------------------------------------------------------
 // thread = (row, j) with j < cw = c/ways + (pad channels of y); consecutive threads walk j so
 // each of the `ways` slice reads and both writes are coalesced runs.
-template <int WAYS>
-__global__ void __launch_bounds__(256) mfm_fwd_k(const float* __restrict__ x, float* __restrict__ y, long rows,
+template <int WAYS, typename T = float>
+__global__ void __launch_bounds__(256) mfm_fwd_k(const T* __restrict__ x, T* __restrict__ y, long rows,
                                                  int c, int cp_in, int cp_out, int cw) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * cw) return;
   const long row = i / cw;
   const int j = (int)(i - row * cw);
   const int cs = c / WAYS;
-  const float* xr = x + row * cp_in;
-  float* yr = y + row * cp_out;
+  const T* xr = x + row * cp_in;
+  T* yr = y + row * cp_out;
   if (j < cs) {
     if (WAYS == 3) {
-      const float s0 = xr[j], s1 = xr[cs + j], s2 = xr[2 * cs + j];
-      yr[j] = fmaxf(fmaxf(s0, s1), s2);
-      yr[cs + j] = fminf(fminf(s0, s1), s2);
+      const float s0 = (float)xr[j], s1 = (float)xr[cs + j], s2 = (float)xr[2 * cs + j];
+      yr[j] = (T)fmaxf(fmaxf(s0, s1), s2);        // max / min of stored values: exact in either element type
+      yr[cs + j] = (T)fminf(fminf(s0, s1), s2);
     } else {
-      yr[j] = fmaxf(xr[j], xr[cs + j]);
+      yr[j] = (T)fmaxf((float)xr[j], (float)xr[cs + j]);
     }
   } else {
     const int cout = (WAYS == 3) ? 2 * cs : cs;
     const int pc = cout + (j - cs);
-    if (pc < cp_out) yr[pc] = 0.f;
+    if (pc < cp_out) yr[pc] = (T)0.f;
   }
 }
 
 // MXNet: d maximum(l,r) -> l if l >= r else r ; d minimum(l,r) -> l if l <= r else r.
 // ORDER_GROUP: max(max(s0,s1),s2); ORDER_RES: max(s2, max(s0,s1)).
-template <int WAYS>
-__global__ void __launch_bounds__(256) mfm_bwd_k(const float* __restrict__ x, const float* __restrict__ dy,
-                                                 const float* __restrict__ add, float* __restrict__ dx, long rows,
+template <int WAYS, typename T = float>
+__global__ void __launch_bounds__(256) mfm_bwd_k(const T* __restrict__ x, const T* __restrict__ dy,
+                                                 const T* __restrict__ add, T* __restrict__ dx, long rows,
                                                  int c, int cp_in, int cp_out, int cw, int order) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * cw) return;
   const long row = i / cw;
   const int j = (int)(i - row * cw);
   const int cs = c / WAYS;
-  const float* xr = x + row * cp_in;
-  const float* gr = dy + row * cp_out;
-  float* dr = dx + row * cp_in;
-  const float* ar = add ? add + row * cp_in : nullptr;
+  const T* xr = x + row * cp_in;
+  const T* gr = dy + row * cp_out;
+  T* dr = dx + row * cp_in;
+  const T* ar = add ? add + row * cp_in : nullptr;
   if (j < cs) {
     if (WAYS == 3) {
-      const float s0 = xr[j], s1 = xr[cs + j], s2 = xr[2 * cs + j];
-      const float gmax = gr[j], gmin = gr[cs + j];
+      const float s0 = (float)xr[j], s1 = (float)xr[cs + j], s2 = (float)xr[2 * cs + j];
+      const float gmax = (float)gr[j], gmin = (float)gr[cs + j];
       int imax = (s0 >= s1) ? 0 : 1;
       int imin = (s0 <= s1) ? 0 : 1;
       const float m1 = fmaxf(s0, s1), n1 = fminf(s0, s1);
@@ -99,18 +99,18 @@ __global__ void __launch_bounds__(256) mfm_bwd_k(const float* __restrict__ x, co
       float d0 = (imax == 0 ? gmax : 0.f) + (imin == 0 ? gmin : 0.f);
       float d1 = (imax == 1 ? gmax : 0.f) + (imin == 1 ? gmin : 0.f);
       float d2 = (imax == 2 ? gmax : 0.f) + (imin == 2 ? gmin : 0.f);
-      if (ar) { d0 += ar[j]; d1 += ar[cs + j]; d2 += ar[2 * cs + j]; }
-      dr[j] = d0; dr[cs + j] = d1; dr[2 * cs + j] = d2;
+      if (ar) { d0 += (float)ar[j]; d1 += (float)ar[cs + j]; d2 += (float)ar[2 * cs + j]; }
+      dr[j] = (T)d0; dr[cs + j] = (T)d1; dr[2 * cs + j] = (T)d2;
     } else {
-      const float s0 = xr[j], s1 = xr[cs + j];
-      const float g = gr[j];
+      const float s0 = (float)xr[j], s1 = (float)xr[cs + j];
+      const float g = (float)gr[j];
       float d0 = (s0 >= s1) ? g : 0.f, d1 = (s0 >= s1) ? 0.f : g;
-      if (ar) { d0 += ar[j]; d1 += ar[cs + j]; }
-      dr[j] = d0; dr[cs + j] = d1;
+      if (ar) { d0 += (float)ar[j]; d1 += (float)ar[cs + j]; }
+      dr[j] = (T)d0; dr[cs + j] = (T)d1;
     }
   } else {
     const int pc = WAYS * cs + (j - cs);  // pad channels of x (c % WAYS == 0 => c == WAYS*cs)
-    if (pc < cp_in) dr[pc] = 0.f;
+    if (pc < cp_in) dr[pc] = (T)0.f;
   }
 }
 
@@ -241,6 +241,43 @@ int efm_mfm_bwd(const float* x, const float* dy, const float* add, float* dx, in
     hipLaunchKernelGGL(mfm_bwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (long)rows, c, cp_in,
                        cp_out, cw, order);
   return efm::check_launch("mfm_bwd");
+}
+
+// bf16 activations (channel stride pad8): the stand-alone MFM of the bf16 plan (EFM-29's residual-block inputs)
+static inline int pad8c(int c) { return (c + 7) & ~7; }
+
+int efm_mfmb_fwd(const uint16_t* x, uint16_t* y, int64_t rows, int c, int ways, void* stream) {
+  EFM_REQUIRE(x && y && rows > 0 && c > 0, "mfmb_fwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfmb_fwd: c=%d not divisible by ways=%d", c, ways);
+  const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
+  const int cp_in = pad8c(c), cp_out = pad8c(cout);
+  const int cw = cs + (cp_out - cout);
+  dim3 grid((unsigned)efm::cdiv(rows * cw, 256));
+  const __bf16* xb = reinterpret_cast<const __bf16*>(x);
+  __bf16* yb = reinterpret_cast<__bf16*>(y);
+  if (ways == 3)
+    hipLaunchKernelGGL((mfm_fwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (long)rows, c, cp_in, cp_out, cw);
+  else
+    hipLaunchKernelGGL((mfm_fwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (long)rows, c, cp_in, cp_out, cw);
+  return efm::check_launch("mfmb_fwd");
+}
+
+int efm_mfmb_bwd(const uint16_t* x, const uint16_t* dy, const uint16_t* add, uint16_t* dx, int64_t rows, int c, int ways, int order,
+                 void* stream) {
+  EFM_REQUIRE(x && dy && dx && rows > 0 && c > 0, "mfmb_bwd: bad argument");
+  EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "mfmb_bwd: c=%d not divisible by ways=%d", c, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "mfmb_bwd: bad order %d", order);
+  const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
+  const int cp_in = pad8c(c), cp_out = pad8c(cout);
+  const int cw = cs + (cp_in - c);
+  dim3 grid((unsigned)efm::cdiv(rows * cw, 256));
+  const __bf16 *xb = reinterpret_cast<const __bf16*>(x), *gb = reinterpret_cast<const __bf16*>(dy), *ab = reinterpret_cast<const __bf16*>(add);
+  __bf16* db = reinterpret_cast<__bf16*>(dx);
+  if (ways == 3)
+    hipLaunchKernelGGL((mfm_bwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (long)rows, c, cp_in, cp_out, cw, order);
+  else
+    hipLaunchKernelGGL((mfm_bwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (long)rows, c, cp_in, cp_out, cw, order);
+  return efm::check_launch("mfmb_bwd");
 }
 
 int efm_maxpool2_fwd(const float* x, float* y, int batch, int h, int w, int c, void* stream) {

@@ -500,3 +500,22 @@ def wino_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=Fa
     check(lib.efm_wino_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(dbias if want_bias else None), int(bool(accumulate)), _p(ws),
                                   ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_wino_bwd_weight")
     return dw, (dbias if want_bias else None)
+
+
+def mfmb_fwd(x, c, ways=3):
+    """Stand-alone MFM on a bf16 NHWC (pad8) activation."""
+    _need_dev(x)
+    p8 = lambda v: (v + 7) & ~7  # noqa: E731
+    assert x.dtype == torch.bfloat16 and x.shape[-1] == p8(c)
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1] + (p8(mfm_out_channels(c, ways)),), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().efm_mfmb_fwd(_p(x), _p(out), rows, c, ways, _stream()), "efm_mfmb_fwd")
+    return out
+
+
+def mfmb_bwd(x, dy, c, ways=3, order=_lib.MFM_ORDER_GROUP, add=None):
+    _need_dev(x, dy, add)
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty_like(x)
+    check(_lib.load().efm_mfmb_bwd(_p(x), _p(dy), _p(add), _p(out), rows, c, ways, order, _stream()), "efm_mfmb_bwd")
+    return out

@@ -41,6 +41,7 @@ class Step:
         self.desc = None
         self.pname = None
         self.no_bias = False
+        self.f32 = False            # bf16 plans: this convolution (the embedding head) runs on the fp32 kernels
         self.needs_grad = False     # does any gradient have to flow into this step's output?
         self.index = -1
 
@@ -215,21 +216,25 @@ class Plan:
                 users[i.index].append(st)
         outs = {st.index for st in self.outputs}
         for st in self.steps:
-            if st.op in ("mfm", "pool"):
-                raise NotImplementedError("bf16 plan: stand-alone %s '%s' (only MFM / pooling fused into a convolution)" % (st.op, st.node.name))
+            if st.op == "pool":
+                raise NotImplementedError("bf16 plan: stand-alone pooling '%s' (only pooling fused into a convolution)" % st.node.name)
+            if st.op == "mfm" and (st.index in outs or any(u.op == "l2norm" for u in users[st.index])):
+                raise NotImplementedError("bf16 plan: a stand-alone MFM may not feed the fp32 head")
             if st.op == "conv":
+                # everything downstream of the L2 normalisation (the embedding head) stays fp32: fp32 kernels, fp32 weights
+                st.f32 = st.inputs[0].op == "l2norm" or getattr(st.inputs[0], "f32", False)
+                if st.f32:
+                    continue
                 feeds_f32 = st.index in outs or any(u.op == "l2norm" for u in users[st.index])
                 if feeds_f32 and st.epi is None:
                     raise NotImplementedError("bf16 plan: a plain convolution may not feed the fp32 head")
-                if st.inputs[0].op == "l2norm":
-                    raise NotImplementedError("bf16 plan: convolution on the fp32 head output")
                 st.out_f32 = feeds_f32
                 st.wb = st.wdb = None
 
     def _cast_weights(self, v):
         """bf16 copies of every weight (forward + data-gradient layouts) from the fp32 master buffer: once per step."""
         for st in self.steps:
-            if st.op == "conv":
+            if st.op == "conv" and not st.f32:
                 need_d = st.inputs[0].needs_grad
                 st.wb, st.wdb = ops.convb_cast_weights(st.desc, v[st.pname + "_weight"], st.wb, st.wdb, need_dgrad=need_d)
 
@@ -311,7 +316,7 @@ class Plan:
         for st in self.steps:
             if st.op == "input":
                 acts[st.index] = ops.nchw_to_nhwc_bf16(x.contiguous()) if bf else ops.nchw_to_nhwc(x.contiguous())
-            elif st.op == "conv" and bf:
+            elif st.op == "conv" and bf and not st.f32:
                 bias = None if st.no_bias else v[st.pname + "_bias"]
                 src = acts[st.inputs[0].index]
                 if st.epi is not None:
@@ -340,7 +345,7 @@ class Plan:
                 else:
                     acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
             elif st.op == "mfm":
-                acts[st.index] = ops.mfm_fwd(acts[st.inputs[0].index], st.inputs[0].shape[0], st.node.attrs["ways"])
+                acts[st.index] = (ops.mfmb_fwd if bf else ops.mfm_fwd)(acts[st.inputs[0].index], st.inputs[0].shape[0], st.node.attrs["ways"])
             elif st.op == "pool":
                 acts[st.index] = ops.maxpool2_fwd(acts[st.inputs[0].index], st.shape[0])
             elif st.op == "l2norm":
@@ -394,7 +399,7 @@ class Plan:
             if st.op == "conv":
                 d = st.desc
                 src = st.inputs[0]
-                bf = self.dtype == "bf16"
+                bf = self.dtype == "bf16" and not st.f32
                 if st.epi is not None:  # gradient of the fused MFM (+ pool) epilogue -> full conv-output gradient
                     dy = (ops.convb_mfm_pool_bwd if bf else ops.mfm_pool_bwd)(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
                 wgrad = ops.convb_bwd_weight if bf else ops.conv_bwd_weight
@@ -439,7 +444,8 @@ class Plan:
             elif st.op == "mfm":
                 src = st.inputs[0]
                 prev = gr.pop(src.index, None)
-                gr[src.index] = ops.mfm_bwd(acts[src.index], dy, src.shape[0], st.node.attrs["ways"], st.node.attrs["order"], add=prev)
+                gr[src.index] = (ops.mfmb_bwd if self.dtype == "bf16" else ops.mfm_bwd)(
+                    acts[src.index], dy, src.shape[0], st.node.attrs["ways"], st.node.attrs["order"], add=prev)
             elif st.op == "pool":
                 src = st.inputs[0]
                 if src.index in gr:

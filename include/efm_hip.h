@@ -168,6 +168,11 @@ int efm_mfm_fwd(const float* x, float* y, int64_t rows, int c, int ways, void* s
 int efm_mfm_bwd(const float* x, const float* dy, const float* add, float* dx, int64_t rows, int c,
                 int ways, int order, void* stream);
 
+/* The same MFM on bf16 activations (channel stride pad8): the residual-block inputs of EFM-29 under the bf16 plan. */
+int efm_mfmb_fwd(const uint16_t* x, uint16_t* y, int64_t rows, int c, int ways, void* stream);
+int efm_mfmb_bwd(const uint16_t* x, const uint16_t* dy, const uint16_t* add, uint16_t* dx, int64_t rows, int c,
+                 int ways, int order, void* stream);
+
 /* Max pooling 2x2 stride 2, 'valid' (floor) — ref: efm_symbol.py:78, lightcnn.py:83. */
 int efm_maxpool2_fwd(const float* x, float* y, int batch, int h, int w, int c, void* stream);
 int efm_maxpool2_bwd(const float* x, const float* dy, float* dx, int batch, int h, int w, int c, void* stream);

@@ -211,3 +211,28 @@ def lightcnn9_forward_bf16(p, x, forced=None, outs=None):
 
 def deepcnn_forward_bf16(p, x, forced=None, outs=None):
     return mfm2_stack_forward_bf16(p, x, DEEPCNN_LAYERS, forced, outs)
+
+
+def efm29_forward_bf16(p, x):
+    """EFM-29 as the bf16 plan computes it (free-running emulation): every STORED activation is bf16 — the fused conv -> MFM3 (-> pool)
+    results, the residual sums `data + conv_res_r(...)` (one rounding, after the fp32 add in the epilogue), the stand-alone MFM3 of a
+    residual-block input (max / min of bf16 values: exact) — weights are bf16 copies of the fp32 masters, accumulation / bias / MFM /
+    pooling decisions are fp32, and the 342-d feature that feeds the fp32 head stays fp32.  Gradients are rounded where they are
+    stored (the `_Round*` functions)."""
+    def conv(cur, name, pad):
+        return _RoundBwd.apply(F.conv2d(cur, _RoundFwd.apply(p[name + "_weight"]), p[name + "_bias"], padding=pad))
+
+    def block(data, lname):
+        e = mfm3(data)                                        # stored bf16 (exact)
+        e = _RoundBoth.apply(mfm3(conv(e, "conv%s_res" % lname, 1)))
+        return _RoundBoth.apply(data + conv(e, "conv%s_res_r" % lname, 1))
+
+    cur = _RoundBoth.apply(x)
+    for num_r, num, k, pad, layer, tar in GROUPS:
+        if num_r > 0:
+            for i in range(tar):
+                cur = block(cur, layer if i == 0 else layer + str(i))
+            cur = _RoundBoth.apply(mfm3(conv(cur, "conv%s_r" % layer, 0)))
+        cur = _RoundBoth.apply(F.max_pool2d(mfm3(conv(cur, "conv%s" % layer, pad)), 2, 2))
+    fc1 = _RoundBwd.apply(F.linear(cur.flatten(1), _RoundFwd.apply(p["fc1_weight"]), p["fc1_bias"]))
+    return mfm3(fc1)
