@@ -946,6 +946,9 @@ __global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restri
 // ---- bf16 weight gradient: C[n][k] = sum_pixels dy[pix][n] * A[pix][k], contraction (MFMA K) = 32 pixels per step.
 // The tiles arrive by LDS-DMA as [pixel][channel] rows; the MFMA wants 8 consecutive PIXELS of one channel per lane, i.e. the
 // transposed image: ds_read_b64_tr_b16 delivers exactly that (4 pixels x 16 channels per 16-lane group, column-major).
+#ifndef WGB_BP
+#define WGB_BP 32  // pixels per contraction step of the bf16 weight gradient (one MFMA K); 64 measured 50 % slower (LightCNN-9 wgrad 2.3 -> 3.5 ms)
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -962,7 +965,7 @@ struct WgradBP {
 
 template <int KPW, int NTW>
 __device__ __forceinline__ void convb_wgrad_body(const WgradBP& p, __bf16* smem) {
-  constexpr int BKR = 64 * KPW, BNW = 16 * NTW, BP = 32;
+  constexpr int BKR = 64 * KPW, BNW = 16 * NTW, BP = WGB_BP;
   constexpr int K8 = BKR / 8, N8 = BNW / 8;          // 16-byte pieces per pixel row
   constexpr int PX = (BP * K8 + 255) / 256, PY = (BP * N8 + 255) / 256;
   constexpr int TILE = BP * (BKR + BNW);              // bf16 elements per stage
@@ -1041,14 +1044,17 @@ __device__ __forceinline__ void convb_wgrad_body(const WgradBP& p, __bf16* smem)
   auto compute = [&](int buf) {
     const __bf16* Xs = smem + buf * TILE;
     const __bf16* Ys = Xs + BP * BKR;
-    bf16x8 bx[KPW];
 #pragma unroll
-    for (int kt = 0; kt < KPW; ++kt) bx[kt] = frag(Xs, BKR, (wave * KPW + kt) * 16);
+    for (int ph = 0; ph < BP / 32; ++ph) {  // 32 pixels (one MFMA K) at a time
+      bf16x8 bx[KPW];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const bf16x8 ay = frag(Ys, BNW, nt * 16);
+      for (int kt = 0; kt < KPW; ++kt) bx[kt] = frag(Xs + ph * 32 * BKR, BKR, (wave * KPW + kt) * 16);
 #pragma unroll
-      for (int kt = 0; kt < KPW; ++kt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ay, bx[kt], acc[kt][nt], 0, 0, 0);
+      for (int nt = 0; nt < NTW; ++nt) {
+        const bf16x8 ay = frag(Ys + ph * 32 * BNW, BNW, nt * 16);
+#pragma unroll
+        for (int kt = 0; kt < KPW; ++kt) acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ay, bx[kt], acc[kt][nt], 0, 0, 0);
+      }
     }
   };
 
@@ -1107,7 +1113,7 @@ __device__ __forceinline__ void bias_colsum_bf16_body(const WgradBP& p, float* r
 
 template <int KPW, int NTW>
 __global__ void __launch_bounds__(256, 2) convb_wgrad_k(const WgradBP p) {
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 32 * (64 * KPW + 16 * NTW)];
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * WGB_BP * (64 * KPW + 16 * NTW)];
   if ((int)blockIdx.x >= p.mma_blocks)
     bias_colsum_bf16_body(p, reinterpret_cast<float*>(smem), (int)blockIdx.x - p.mma_blocks);
   else
@@ -1165,7 +1171,7 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
   const int max_splits = std::min(1024, (M + 1023) / 1024);  // >= 32 contraction steps per block; > 32 slabs reduce in two levels
   splits = std::max(1, std::min(splits, max_splits));
   int mps = (M + splits - 1) / splits;
-  mps = (mps + 31) & ~31;
+  mps = (mps + WGB_BP - 1) / WGB_BP * WGB_BP;
   pl.m_per_split = mps;
   pl.splits = (M + mps - 1) / mps;
   pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
