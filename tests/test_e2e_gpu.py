@@ -235,3 +235,45 @@ def test_config1_64_faces_vs_committed_golden():
     dl, dr = loss.cpu().numpy() - 0.2, z["loss"] - 0.2
     print("config-1 golden: emb %.2e, (loss - margin) %.2e of %.2e" % (e_emb, np.abs(dl - dr).max(), np.abs(dr).max()))
     assert np.abs(dl - dr).max() < 1e-3 * np.abs(dr).max() + 1e-7
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] at its full size (256 images of 3x112x112): properties that need no oracle run.
+    (a) a batch permutation permutes the embeddings bit for bit (no result depends on the position of an image in the batch);
+    (b) the parameter gradient of a step is bitwise reproducible and equals the sum of the gradients of its two half-batch shards
+        with the same negatives (the data-parallel contract), to fp32 summation noise;
+    (c) the weight gradient is linear in the upstream gradient."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    batch, image = 256, 112
+    tr = TripletTrainer(batch, image=image, seed=42)
+    x = synth.images(batch, 3, image, 1234)
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(0)).cuda()
+    emb, _ = tr.plan.forward(x, tr.flat, train=False)
+    emb = emb.clone()
+    emb_p, _ = tr.plan.forward(x[perm].contiguous(), tr.flat, train=False)
+    assert torch.equal(emb_p, emb[perm])
+    assert torch.isfinite(emb).all() and float((emb.norm(dim=1) - 0).abs().min()) > 0
+    demb = (synth.uniform01(batch * emb.shape[1], 77).view(batch, -1) * 2 - 1)[:, :emb.shape[1]].contiguous()
+    neg = synth.negative_indices(synth.parity_labels(batch), 5).cuda()
+
+    def grad_of(scale):
+        tr.forward_loss(x, neg)
+        tr.backward(demb=demb * scale)
+        return tr.grad.clone()
+    g1 = grad_of(1.0)
+    assert torch.equal(g1, grad_of(1.0))                                   # (b) reproducible
+    g2 = grad_of(2.0)
+    assert rel_err(g2.cpu().numpy(), 2 * g1.cpu().numpy()) < 1e-5          # (c) linear in the upstream gradient
+    # (b) shards: two 128-image trainers on the halves, upstream gradients of their rows
+    half = batch // 2
+    tr_h = TripletTrainer(half, image=image, seed=42)
+    tr_h.flat.copy_(tr.flat)
+    gsum = torch.zeros_like(g1)
+    neg_h = synth.negative_indices(synth.parity_labels(half), 5).cuda()
+    for s in range(2):
+        rows = slice(s * half, (s + 1) * half)
+        tr_h.forward_loss(x[rows].contiguous(), neg_h)
+        tr_h.backward(demb=demb[rows].contiguous())
+        gsum += tr_h.grad
+    assert rel_err(gsum.cpu().numpy(), g1.cpu().numpy()) < 1e-4
