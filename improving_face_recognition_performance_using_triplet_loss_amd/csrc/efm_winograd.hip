@@ -788,7 +788,7 @@ WinoPlan plan_wino(int cin_p, int cout, int tune, int ways = 0) {
   pl.variant = wino_variant(tune);
   pl.cn = 0;
   if (ways > 0) {  // fused epilogue: a block holds `ways` slices of cn channels; as few blocks as the widest tile allows
-    static const int max8 = [] { const char* e = getenv("EFM_WINO_NTB"); return e ? atoi(e) : 5; }();
+    static const int max8 = [] { const char* e = getenv("EFM_WINO_NTB"); return std::min(5, std::max(3, e ? atoi(e) : 5)); }();
     const int maxnb = (pl.variant == 4) ? 48 : 16 * max8;
     const int cs = cout / ways;
     pl.nblocks = (cs + maxnb / ways - 1) / (maxnb / ways);
@@ -807,7 +807,7 @@ WinoPlan plan_wino(int cin_p, int cout, int tune, int ways = 0) {
     pl.kpad = cin_p;
     return pl;
   }
-  static const int max_ntb = [] { const char* e = getenv("EFM_WINO_NTB"); return e ? atoi(e) : 5; }();
+  static const int max_ntb = [] { const char* e = getenv("EFM_WINO_NTB"); return std::min(5, std::max(3, e ? atoi(e) : 5)); }();
   pl.nblocks = (tiles + max_ntb - 1) / max_ntb;
   pl.NTB = std::max(3, (tiles + pl.nblocks - 1) / pl.nblocks);
   pl.n_rows = pl.nblocks * pl.NTB * 16;
@@ -839,7 +839,7 @@ int run_wino(const float* x, const float* u, const float* bias, const float* res
   case N:                                                                  \
     hipLaunchKernelGGL((wino_fwd_k<N>), grid, dim3(512), 0, s, p);         \
     break;
-    EFM_CASE(3) EFM_CASE(4) EFM_CASE(5) EFM_CASE(6)
+    EFM_CASE(3) EFM_CASE(4) EFM_CASE(5)  // 6 tiles would fill the LDS exactly (160 KB) but spill accumulators
 #undef EFM_CASE
     default:
       efm::set_error("wino: unsupported NTB=%d", pl.NTB);
