@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
 
     _fields_ = [(n, c_int32) for n in (
         "batch", "hin", "win", "cin", "cin_p", "hout", "wout", "cout", "cout_p",
-        "kh", "kw", "pad_h", "pad_w", "n_pad16", "k_pad", "dn_pad16", "dk_pad", "tune_fwd", "tune_dgrad")]
+        "kh", "kw", "pad_h", "pad_w", "n_pad16", "k_pad", "dn_pad16", "dk_pad", "tune_fwd", "tune_dgrad", "tune_wgrad")]
 
 
 # name -> (restype, argtypes); the single source the symbol-export test checks against the header.

@@ -864,6 +864,7 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   // 8 k-tiles per block whenever that saves a k-block: dy is re-read once per k-block, and the narrow-K layers
   // (conv1: K = 100, the 1x1 convolutions) are bound by exactly that traffic.
   pl.KPW = env_int("EFM_WGRAD_KPW", (ktiles >= 5) ? 2 : 1);
+  if ((d->tune_wgrad & 15) == 1 || (d->tune_wgrad & 15) == 2) pl.KPW = d->tune_wgrad & 15;
   if (pl.KPW != 2) pl.KPW = 1;
   pl.kblocks = (ktiles + 4 * pl.KPW - 1) / (4 * pl.KPW);
   const int nb = (ntiles + 12) / 13;
@@ -871,7 +872,7 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
   // measured on EFM-29 @ B=256: ~10 blocks per CU, but never fewer than 768 pixels (48 K steps) per block
-  const int target = env_int("EFM_WGRAD_BLOCKS", 2560);
+  const int target = (d->tune_wgrad >> 4) > 0 ? 64 * (d->tune_wgrad >> 4) : env_int("EFM_WGRAD_BLOCKS", 2560);
   int splits = (target + base - 1) / base;
   const int max_splits = (M + 767) / 768;
   if (splits > max_splits) splits = max_splits;
@@ -1239,6 +1240,7 @@ int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, i
   d->dk_pad = efm_pad16(kh * kw * d->cout_p);
   d->tune_fwd = 0;
   d->tune_dgrad = 0;
+  d->tune_wgrad = 0;
   EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 30) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 30),
               "conv_desc_init: tensor exceeds 2^30 elements (4 GiB buffer descriptors)");
   EFM_REQUIRE(d->k_pad < 65536 && d->dk_pad < 65536, "conv_desc_init: K = kh*kw*channels must stay below 65536");

@@ -516,7 +516,7 @@ class Plan:
             d = st.desc
             key = (d.hin, d.win, d.cin, d.cout, d.kh, d.pad_h, st.epi is not None, st.inputs[0].needs_grad)
             if key in seen:
-                d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad = seen[key]
+                d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad, d.tune_wgrad = seen[key]
                 continue
             st.wino_fwd = st.wino_dgrad = False
             x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=self.device)
@@ -577,7 +577,12 @@ class Plan:
                         chosen[st.pname + ":dgrad"] = "winograd/%d" % (8 if var == 1 else 4)
                     else:
                         d.tune_dgrad = win
-            seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad)
+            # weight gradient: 64 / 128 weight columns per block x the number of pixel splits (summation order differs, nothing else)
+            dwt = torch.empty((d.n_pad16, d.k_pad), device=self.device)
+            dbt = torch.empty((d.n_pad16,), device=self.device)
+            cw = [0] + [kpw | ((blocks // 64) << 4) for kpw in (1, 2) for blocks in (1536, 2560, 3840)]
+            chosen[st.pname + ":wgrad"] = best(lambda: ops.conv_bwd_weight(d, x, dy, dw=dwt, dbias=dbt), d, "tune_wgrad", cw)[0]
+            seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad, d.tune_wgrad)
         if verbose:
             print("[efm autotune]", {k: v for k, v in chosen.items() if v})
         return chosen

@@ -79,6 +79,10 @@ typedef struct efm_conv_desc {
    * MT in {1,2} (64- or 128-pixel tiles) and nsplit = number of channel blocks.  Any choice gives bit-identical results
    * (the K order of every output element is fixed); the host may time the candidates once and store the winner here. */
   int32_t tune_fwd, tune_dgrad;
+  /* Same for efm_conv_bwd_weight (and its workspace size, which depends on it): 0 = heuristic, else KPW | (blocks64 << 4) with
+   * KPW in {1,2} (64 or 128 weight columns per block) and blocks64 = target number of thread blocks / 64 (0 = default 2560).
+   * Every choice is deterministic; different choices differ by fp32 summation order. */
+  int32_t tune_wgrad;
 } efm_conv_desc;
 
 /* Fill every derived field (hout = hin + 2*pad_h - kh + 1, paddings, packed sizes). */
