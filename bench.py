@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 (lightcnn9 only) = BASELINE configs[2]: bf16 operands / activations, fp32 accumulate + master weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="images of the CPU-baseline sample (~15 s of host work)")
     return ap.parse_args()
 
 
