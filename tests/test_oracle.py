@@ -258,3 +258,32 @@ def test_oracle_reproduces_config1_golden_rows():
     p32 = {k: v.astype(np.float32) for k, v in params.items()}
     _, emb32 = M.forward(p32, w_head.astype(np.float32), x.astype(np.float32))
     assert np.abs(emb32 - z["emb"][rows]).max() < 1e-4 * np.abs(z["emb"]).max()
+
+
+@pytest.mark.parametrize("nshards", [2, 4])
+def test_shard_gradients_sum_to_the_full_batch_gradient(nshards):
+    """The data-parallel contract (SURVEY §8c iv / §8e): with negatives local to a shard, as the reference draws them
+    (train_efm.py:234-239), the per-shard parameter gradients SUM to the single-process gradient of the same triplets — fp64."""
+    import torch
+    from oracle import efm_oracle_torch as OT
+    image, anchors = 32, 8
+    params = O.init_params(O.efm29_param_shapes(3, image), 42)
+    wh = O.uniform_pm((128, 342), 777, O.xavier_uniform_scale((128, 342)))
+    x = O.uniform01(2 * anchors * 3 * image * image, 9).reshape(2 * anchors, 3, image, image)
+    per = anchors // nshards
+    neg_local = (np.arange(per) + 1) % per                      # inside a shard: the next anchor of that shard
+    neg_full = np.concatenate([s * per + neg_local for s in range(nshards)])
+
+    def grads(xs, neg):
+        tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+        twh = torch.tensor(wh, requires_grad=True)
+        OT.train_step(tp, twh, torch.tensor(xs), torch.tensor(neg.astype(np.int64)), 0.2)
+        return {**{k: t.grad.numpy() for k, t in tp.items()}, "head": twh.grad.numpy()}
+    full = grads(x, neg_full)
+    total = None
+    for s in range(nshards):
+        rows = np.concatenate([np.arange(s * per, (s + 1) * per), anchors + np.arange(s * per, (s + 1) * per)])  # its anchors ; its positives
+        g = grads(x[rows], neg_local)
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+    for k in full:
+        assert np.abs(total[k] - full[k]).max() <= 1e-10 * (np.abs(full[k]).max() + 1e-30), k
