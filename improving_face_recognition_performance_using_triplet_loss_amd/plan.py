@@ -509,6 +509,8 @@ class Plan:
 
         wino = self.dtype == "f32" and os.environ.get("EFM_WINO", "1") != "0"
         force = os.environ.get("EFM_WINO") == "force"  # tests: Winograd wherever it applies, whatever the clock says
+        # data gradients run next to the weight-gradient kernels of the side stream: which Winograd variants to time for them
+        dgrad_vars = tuple(int(v) for v in os.environ.get("EFM_WINO_DGRAD_VARIANTS", "1,2").split(","))
         seen = {}
         for st in self.steps:
             if st.op != "conv":
@@ -566,7 +568,7 @@ class Plan:
                 if wino and ops.wino_supported(d):
                     tw = {}
                     wf = torch.rand((d.n_pad16, d.k_pad), device=self.device)
-                    for var in (1, 2):
+                    for var in dgrad_vars:
                         d.tune_dgrad = var << 8
                         u = ops.wino_make_u(d, wf, dgrad=True)
                         tw[var] = timed(lambda: ops.wino_bwd_data(d, dy, u, out=dx))
