@@ -113,3 +113,27 @@ def test_deepcnn_lfw_runner_bf16(tmp_path):
     assert all(0.3 <= a <= 1.0 for a in accs)
     assert accs[-1] >= 0.9, accs      # held-out identities verify after 120 steps (0.775 untrained)
     assert "triplets/s" in r.stdout
+
+
+def test_extract_features_dropin_writes_the_reference_csv_format(tmp_path):
+    """extract_feacture_v2.py drop-in: 342 comma-terminated floats per row (unit L2 norm), one label per line, and the files read
+    back through the CSV iterator pre-trained_efm_v3.py uses (the reference's producer / consumer pair)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "extract_feacture_v2.py"), str(tmp_path), str(tmp_path), "--synthetic", "48",
+                        "--batch-size", "16", "--image-size", "64"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("[batch") == 6 and "train acc" in r.stdout
+    for tag in ("train", "valid"):
+        lines = open(tmp_path / ("feature_vector_%s.csv" % tag)).read().splitlines()
+        assert len(lines) == 48
+        for ln in lines[:5]:
+            assert ln.endswith(",")
+            vals = np.array([float(v) for v in ln.rstrip(",").split(",")])
+            assert vals.shape == (342,) and abs(np.linalg.norm(vals) - 1.0) < 1e-5
+        labels = open(tmp_path / ("label_%s.csv" % tag)).read().splitlines()
+        assert len(labels) == 48 and float(labels[0]) == float(int(float(labels[0])))
+    from improving_face_recognition_performance_using_triplet_loss_amd.data import CSVIter
+    it = CSVIter(str(tmp_path / "feature_vector_train.csv"), str(tmp_path / "label_train.csv"), 16, 342)
+    b = next(iter(it))
+    assert tuple(b.data[0].shape) == (16, 342)
