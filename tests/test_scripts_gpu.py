@@ -137,3 +137,19 @@ def test_extract_features_dropin_writes_the_reference_csv_format(tmp_path):
     it = CSVIter(str(tmp_path / "feature_vector_train.csv"), str(tmp_path / "label_train.csv"), 16, 342)
     b = next(iter(it))
     assert tuple(b.data[0].shape) == (16, 342)
+
+
+def test_cosine_similarity_test_script_dropin(tmp_path):
+    """test_efm_v2.py drop-in on synthetic features: one "s_ap s_an" row per anchor, cosines in [-1, 1], positives of the same
+    identity (the pairer keeps one positive per identity, so s_ap = 1 whenever the anchor is that very sample)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test_efm_v2.py"), "--synthetic", "4096", "--batch-size", "1024"],
+                       capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("[batch") == 4
+    rows = [ln.split() for ln in open(tmp_path / "cosine_similarity.csv").read().splitlines()]
+    assert len(rows) == 4096 and all(len(r_) == 2 for r_ in rows)
+    v = np.array(rows, dtype=np.float64)
+    assert np.all(np.abs(v) <= 1.0 + 1e-5)
+    assert (v[:, 0] > 0.999).sum() >= 4096 // 16          # anchors that are their identity's stored positive
