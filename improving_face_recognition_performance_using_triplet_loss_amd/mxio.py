@@ -212,3 +212,179 @@ class ImageRecordIter:
 
     def reset(self):
         self.pos = 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MXNet `-symbol.json` (the graph half of a checkpoint: mx.callback.do_checkpoint / mx.sym.load, ref: mutli_gpu_v3.py:160,
+# final_efm.py:205-211, extract_feacture_v2.py:47-51).  Export expands the one-node MFM of graph.py into the reference's
+# SliceChannel / maximum / minimum / Concat idiom (efm_symbol.py:25-30, 68-77) with its operand order; import folds that idiom
+# back, so a file written by the reference's own builder loads onto the fused kernels.  Parity UNPINNED: the reference holds no
+# .json file (only the builder code and two PDFs of the graph); the schema below is MXNet 1.x's (nodes / arg_nodes /
+# node_row_ptr / heads, attrs as strings) and a round trip through it is what the tests check.
+def save_symbol(path, outputs):
+    """Write the network whose output nodes are `outputs` (graph.Sym) as an MXNet symbol JSON file."""
+    import json
+
+    from . import graph as G
+    nodes, out_of = [], {}          # out_of[sym id] = (node index, output index)
+
+    def add(op, name, inputs=(), attrs=None):
+        n = {"op": op, "name": name, "inputs": [[i, o, 0] for i, o in inputs]}
+        if attrs:
+            n["attrs"] = {k: str(v) for k, v in attrs.items()}
+        nodes.append(n)
+        return len(nodes) - 1
+
+    def tup(v):
+        return "(%d, %d)" % (v[0], v[1])
+
+    for s in G.topo_sort(list(outputs)):
+        ins = [out_of[i.id] for i in s.inputs]
+        if s.op == "var":
+            out_of[s.id] = (add("null", s.name), 0)
+        elif s.op in ("conv", "fc"):
+            w = add("null", s.name + "_weight")
+            extra = [(w, 0)]
+            if not s.attrs.get("no_bias"):
+                extra.append((add("null", s.name + "_bias"), 0))
+            if s.op == "conv":
+                a = {"kernel": tup(s.attrs["kernel"]), "num_filter": s.attrs["num_filter"], "pad": tup(s.attrs["pad"]),
+                     "stride": tup(s.attrs.get("stride", (1, 1)))}
+                if s.attrs.get("no_bias"):
+                    a["no_bias"] = "True"
+                out_of[s.id] = (add("Convolution", s.name, ins + extra, a), 0)
+            else:
+                a = {"num_hidden": s.attrs["num_hidden"]}
+                if s.attrs.get("no_bias"):
+                    a["no_bias"] = "True"
+                out_of[s.id] = (add("FullyConnected", s.name, ins + extra, a), 0)
+        elif s.op == "mfm":
+            ways, order = s.attrs["ways"], s.attrs.get("order", G.ORDER_GROUP)
+            sl = add("SliceChannel", "slice_" + s.name, ins, {"axis": 1, "num_outputs": ways})
+            mx1 = add("_maximum", s.name if ways == 2 else s.name + "_max1", [(sl, 0), (sl, 1)])
+            if ways == 2:
+                out_of[s.id] = (mx1, 0)
+                continue
+            mn1 = add("_minimum", s.name + "_min1", [(sl, 0), (sl, 1)])
+            if order == G.ORDER_GROUP:      # maximum(max1, s2)        ref: efm_symbol.py:70-73
+                mx2 = add("_maximum", s.name + "_max2", [(mx1, 0), (sl, 2)])
+                mn2 = add("_minimum", s.name + "_min2", [(mn1, 0), (sl, 2)])
+            else:                           # maximum(s2, max1)        ref: efm_symbol.py:26-29
+                mx2 = add("_maximum", s.name + "_max2", [(sl, 2), (mx1, 0)])
+                mn2 = add("_minimum", s.name + "_min2", [(sl, 2), (mn1, 0)])
+            out_of[s.id] = (add("Concat", s.name, [(mx2, 0), (mn2, 0)], {"dim": 1, "num_args": 2}), 0)
+        elif s.op == "pool":
+            out_of[s.id] = (add("Pooling", s.name, ins, {"kernel": "(2, 2)", "pool_type": "max", "stride": "(2, 2)"}), 0)
+        elif s.op == "add":
+            out_of[s.id] = (add("elemwise_add", s.name, ins), 0)
+        elif s.op == "l2norm":
+            out_of[s.id] = (add("L2Normalization", s.name, ins, {"mode": "instance"}), 0)
+        else:
+            raise ValueError("save_symbol: no MXNet operator for '%s'" % s.op)
+    row, ptr = [0], 0
+    for n in nodes:
+        ptr += int(n.get("attrs", {}).get("num_outputs", 1)) if n["op"] == "SliceChannel" else 1
+        row.append(ptr)
+    doc = {"nodes": nodes, "arg_nodes": [i for i, n in enumerate(nodes) if n["op"] == "null"], "node_row_ptr": row,
+           "heads": [[out_of[o.id][0], out_of[o.id][1], 0] for o in outputs], "attrs": {"mxnet_version": ["int", 10301]}}
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=2)
+
+
+_MAX_OPS = ("_maximum", "_Maximum", "maximum", "broadcast_maximum")
+_MIN_OPS = ("_minimum", "_Minimum", "minimum", "broadcast_minimum")
+_ADD_OPS = ("elemwise_add", "_plus", "_Plus", "broadcast_add", "_add")
+
+
+def load_symbol(path, outputs=None):
+    """Read an MXNet symbol JSON file -> list of graph.Sym output nodes (the file's heads, or the internals named in `outputs`, e.g.
+    ["fc2_output", "concat29_output"] as final_efm.py:207-210 picks them).  Handles the operators the reference's builders emit;
+    Flatten / Dropout / SoftmaxOutput pass through (the plan flattens in FullyConnected, dropout and softmax belong to the id head)."""
+    import ast
+    import json
+
+    from . import graph as G
+    doc = json.load(open(path))
+    nodes = doc["nodes"]
+
+    def attrs(n):
+        return n.get("attrs") or n.get("attr") or n.get("param") or {}
+
+    built = {}
+
+    def entry(e):
+        return build(e[0], e[1])
+
+    def is_slice_out(e, sl, k):
+        return e[0] == sl and e[1] == k
+
+    def fold_mfm(i):
+        """nodes[i] is a Concat or a maximum: recognise the MFM idiom, return the Sym or None."""
+        n = nodes[i]
+        if n["op"] in _MAX_OPS:                                   # MFM2: maximum(slice[0], slice[1])
+            a, b = n["inputs"]
+            sl = a[0]
+            if nodes[sl]["op"] == "SliceChannel" and int(attrs(nodes[sl]).get("num_outputs", 0)) == 2 and b[0] == sl and (a[1], b[1]) == (0, 1):
+                return G.MFM(entry(nodes[sl]["inputs"][0]), 2, G.ORDER_GROUP, name=n["name"])
+            return None
+        if n["op"] != "Concat" or len(n["inputs"]) != 2:
+            return None
+        mx2, mn2 = nodes[n["inputs"][0][0]], nodes[n["inputs"][1][0]]
+        if mx2["op"] not in _MAX_OPS or mn2["op"] not in _MIN_OPS:
+            return None
+
+        def tree(top, ops):
+            """-> (slice node, order) if top = op(op(s0, s1), s2) [GROUP] or op(s2, op(s0, s1)) [RES]."""
+            a, b = top["inputs"]
+            for inner, other, order in ((a, b, G.ORDER_GROUP), (b, a, G.ORDER_RES)):
+                m1 = nodes[inner[0]]
+                if m1["op"] in ops and nodes[other[0]]["op"] == "SliceChannel" and other[1] == 2:
+                    sl = other[0]
+                    x, y = m1["inputs"]
+                    if is_slice_out(x, sl, 0) and is_slice_out(y, sl, 1) and int(attrs(nodes[sl]).get("num_outputs", 0)) == 3:
+                        return sl, order
+            return None
+        t1, t2 = tree(mx2, _MAX_OPS), tree(mn2, _MIN_OPS)
+        if t1 is None or t2 is None or t1 != t2:
+            return None
+        return G.MFM(entry(nodes[t1[0]]["inputs"][0]), 3, t1[1], name=n["name"])
+
+    def build(i, out=0):
+        if (i, out) in built:
+            return built[(i, out)]
+        n = nodes[i]
+        op, a = n["op"], attrs(n)
+        data_in = [e for e in n["inputs"] if nodes[e[0]]["op"] != "null" or not nodes[e[0]]["name"].endswith(("_weight", "_bias", "_label"))]
+        if op == "null":
+            s = G.Variable(n["name"])
+        elif op == "Convolution":
+            k, p = ast.literal_eval(a["kernel"]), ast.literal_eval(a.get("pad", "(0, 0)"))
+            st = ast.literal_eval(a.get("stride", "(1, 1)"))
+            s = G.Convolution(entry(data_in[0]), int(a["num_filter"]), tuple(k), n["name"], pad=tuple(p), stride=tuple(st),
+                              no_bias=str(a.get("no_bias", "False")) == "True")
+        elif op == "FullyConnected":
+            s = G.FullyConnected(entry(data_in[0]), int(a["num_hidden"]), n["name"], no_bias=str(a.get("no_bias", "False")) == "True")
+        elif op == "Pooling":
+            if a.get("pool_type", "max") != "max" or ast.literal_eval(a.get("kernel", "(2, 2)")) != (2, 2):
+                raise ValueError("load_symbol: only 2x2 max pooling is on the path (node %s)" % n["name"])
+            s = G.Pooling(entry(data_in[0]), name=n["name"])
+        elif op in _ADD_OPS:
+            s = entry(data_in[0]) + entry(data_in[1])
+            s.name = n["name"]
+        elif op in ("Flatten", "Dropout", "SoftmaxOutput", "identity", "_copy"):
+            s = entry(data_in[0])
+        elif op == "L2Normalization":
+            s = G.L2Normalization(entry(data_in[0]), name=n["name"])
+        elif op in _MAX_OPS or op == "Concat":
+            s = fold_mfm(i)
+            if s is None:
+                raise ValueError("load_symbol: '%s' (%s) is not part of a max / min feature-map idiom" % (n["name"], op))
+        else:
+            raise ValueError("load_symbol: operator '%s' (node %s) is not on the path" % (op, n["name"]))
+        built[(i, out)] = s
+        return s
+
+    if outputs is None:
+        return [build(h[0], h[1]) for h in doc["heads"]]
+    by_name = {n["name"] + "_output": i for i, n in enumerate(nodes)}
+    return [build(by_name[o]) for o in outputs]

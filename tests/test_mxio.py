@@ -49,3 +49,31 @@ def test_lst_reader(tmp_path):
     p.write_text("0\t3.000000\tid3/a.jpg\n1\t7.000000\tid7/b.jpg\n")
     rows = mxio.read_lst(str(p))
     assert rows == [(0, [3.0], "id3/a.jpg"), (1, [7.0], "id7/b.jpg")]
+
+
+def test_symbol_json_round_trip_efm29_and_mfm2(tmp_path):
+    """EFM-29 (both MFM operand orders, residual adds, the id head) and LightCNN-9 (MFM2) survive save_symbol -> load_symbol:
+    same parameter table, same lowered plan, the MFM idiom folds back into one node per occurrence."""
+    import json
+
+    from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol, mxio
+    from improving_face_recognition_performance_using_triplet_loss_amd.plan import Plan
+    for name, outs in (("efm", efm_symbol.get_net(10)), ("l9", efm_symbol.lightcnn9_embedding_net())):
+        path = str(tmp_path / (name + "-symbol.json"))
+        mxio.save_symbol(path, outs)
+        doc = json.load(open(path))
+        ops_used = {n["op"] for n in doc["nodes"]}
+        assert {"Convolution", "SliceChannel", "_maximum", "Pooling", "FullyConnected"} <= ops_used
+        assert len(doc["node_row_ptr"]) == len(doc["nodes"]) + 1 and all(doc["nodes"][i]["op"] == "null" for i in doc["arg_nodes"])
+        back = mxio.load_symbol(path)
+        p0 = Plan(outs, (2, 3, 112, 112), device="cpu")
+        p1 = Plan(back, (2, 3, 112, 112), device="cpu")
+        assert list(p0.params) == list(p1.params)
+        assert [(s.op, s.shape, bool(s.epi), s.residual is not None) for s in p0.steps] == \
+               [(s.op, s.shape, bool(s.epi), s.residual is not None) for s in p1.steps]
+        assert [s.epi for s in p0.steps] == [s.epi for s in p1.steps]           # ways / order / pool of every fused epilogue
+        assert p0.flops_fwd == p1.flops_fwd
+    # internals by name, as final_efm.py:207-210 / extract_feacture_v2.py:49-50 pick them
+    path = str(tmp_path / "efm-symbol.json")
+    heads = mxio.load_symbol(path, outputs=["fc2_output"])
+    assert heads[0].op == "fc" and heads[0].name == "fc2"
