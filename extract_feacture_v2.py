@@ -87,8 +87,10 @@ def main(argv=None):
         from improving_face_recognition_performance_using_triplet_loss_amd import mxio
         try:
             feat = mxio.load_symbol(js, outputs=["concat29_output"])[0]
-        except KeyError:
+        except KeyError:  # a graph written by this package names the node differently: the 342-d feature is what feeds fc2
             feat = mxio.load_symbol(js)[-1]
+            if feat.op == "fc" and feat.name == "fc2":
+                feat = feat.inputs[0]
     else:
         data = efm_symbol.G.Variable("data")
         feat, _ = efm_symbol.efm_feature(data)

@@ -153,3 +153,32 @@ def test_cosine_similarity_test_script_dropin(tmp_path):
     v = np.array(rows, dtype=np.float64)
     assert np.all(np.abs(v) <= 1.0 + 1e-5)
     assert (v[:, 0] > 0.999).sum() >= 4096 // 16          # anchors that are their identity's stored positive
+
+
+def test_mutli_gpu_v3_dropin_trains_and_checkpoints(tmp_path):
+    """mutli_gpu_v3.py drop-in (softmax pre-training of the Symbol EFM-29): Module.fit-style log lines, a loadable checkpoint pair
+    (symbol JSON + "arg:"-keyed params), and the checkpoint feeds extract_feacture_v2.py (the reference's chain)."""
+    import subprocess
+    import sys
+    from improving_face_recognition_performance_using_triplet_loss_amd import mxio
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "mutli_gpu_v3.py"), "--synthetic", "160", "--epochs", "2", "--batch-size", "20",
+                        "--image-size", "64", "--classes", "4", "--out-dir", str(tmp_path / "run")], capture_output=True, text=True, timeout=900,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Epoch[1] Train-accuracy=" in r.stdout and "Epoch[1] Validation-accuracy=" in r.stdout and "Saved checkpoint" in r.stdout
+    prefix = tmp_path / "run" / "model" / "try2_efm_light_29"
+    params = mxio.load_params(str(prefix) + "-0002.params")
+    assert params["conv1_weight"].shape == (99, 3, 5, 5) and params["fc2_weight"].shape == (4, 342)
+    heads = mxio.load_symbol(str(prefix) + "-symbol.json")
+    assert heads[0].name == "fc2"
+    # the chain: the checkpoint as EFM_RES.{json,params} drives the feature dump
+    model = tmp_path / "model"
+    model.mkdir()
+    os.replace(str(prefix) + "-symbol.json", model / "EFM_RES.json")
+    os.replace(str(prefix) + "-0002.params", model / "EFM_RES.params")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "extract_feacture_v2.py"), str(tmp_path), str(model), "--synthetic", "32",
+                        "--batch-size", "16", "--image-size", "64", "--channels", "3"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "acc nan" not in r.stdout          # the id head came with the checkpoint
+    rows = open(tmp_path / "feature_vector_train.csv").read().splitlines()
+    assert len(rows) == 32 and len(rows[0].rstrip(",").split(",")) == 342
