@@ -182,3 +182,20 @@ def test_mutli_gpu_v3_dropin_trains_and_checkpoints(tmp_path):
     assert "acc nan" not in r.stdout          # the id head came with the checkpoint
     rows = open(tmp_path / "feature_vector_train.csv").read().splitlines()
     assert len(rows) == 32 and len(rows[0].rstrip(",").split(",")) == 342
+
+
+def test_final_efm_dropin(tmp_path):
+    """final_efm.py drop-in: frozen backbone + trainable Dense(342) head on the triplet loss; reference outputs present and the head moves."""
+    import subprocess
+    import sys
+    from improving_face_recognition_performance_using_triplet_loss_amd import mxio
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "final_efm.py"), str(tmp_path), str(tmp_path), "--synthetic", "64", "--epochs", "2",
+                        "--batch-size", "8", "--image-size", "64"], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Epoch 1: train loss" in r.stdout
+    rows = open(tmp_path / "cosine_similarity.csv").read().splitlines()
+    assert len(rows) == 2 * (64 // 8) * 8 and len(rows[0].split()) == 2
+    w0 = mxio.load_params(str(tmp_path / "fc_efm_res-0000.params"))["dense0_weight"]
+    w1 = mxio.load_params(str(tmp_path / "fc_efm_res-0001.params"))["dense0_weight"]
+    assert w0.shape == (342, 342) and np.abs(w1 - w0).max() > 0
+    assert len(open(tmp_path / "curves.csv").read().splitlines()) == 3
