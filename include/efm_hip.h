@@ -128,7 +128,10 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
                         float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * bf16 tensor-core path (BASELINE configs[2]: "bf16 — MFMA conv path").  Same operators, different storage:
+ * bf16 tensor-core path (BASELINE configs[2]: "bf16 — MFMA conv path").  Same operators and the same reference call sites as
+ * the fp32 entry points above (mx.symbol.Convolution efm_symbol.py:32,41,54,62,65,67, FullyConnected :94, nn.Conv2D
+ * lightcnn.py:14-15,47-48, the MFM idiom efm_symbol.py:25-30,63-64, Pooling :78) — the reference has no reduced-precision
+ * mode of its own, this is MXNet AMP's role (`amp.init()` + bf16 cast of a Symbol).  Different storage:
  *   activations  bf16 NHWC, channel stride pad8(c), pads zero;        (uint16_t* here = raw bf16 bits)
  *   weights      bf16 packed wb[n][k], k = tap*pad8(cin) + ci, pad16(cout) rows of pad32(taps*pad8(cin)) elements,
  *                cast every step from the fp32 master weights (which stay in the fp32 packed layout, as do all gradients);
