@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "efm_common.h"
 
 namespace {
@@ -85,7 +87,14 @@ struct Predictor {
   std::vector<void*> owned;
   uint32_t out_shape[2] = {0, 0};
   hipStream_t stream = nullptr;
+  // The forward is ~45 fixed launches on fixed buffers: captured once into a HIP graph and replayed (a single-image forward is
+  // launch-bound: the deployment case of Feature.hpp).  graph_state: 0 = not tried, 1 = captured, -1 = capture unavailable.
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_state = 0;
   ~Predictor() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -240,9 +249,7 @@ int efm_pred_set_input(void* handle, const char* key, const float* data, uint32_
   return EFM_OK;
 }
 
-int efm_pred_forward(void* handle) {
-  Predictor* P = (Predictor*)handle;
-  EFM_REQUIRE(P, "pred_forward: null handle");
+static int pred_enqueue(Predictor* P) {
   int rc = efm_nchw_to_nhwc(P->x_nchw, P->x_nhwc, P->batch, P->c, P->h, P->w, P->stream);
   for (size_t i = 0; rc == EFM_OK && i < P->ops.size(); ++i) {
     const Op& op = P->ops[i];
@@ -254,6 +261,37 @@ int efm_pred_forward(void* handle) {
       rc = efm_mfm_fwd(op.in, op.out, op.rows, op.c, 3, P->stream);
   }
   return rc;
+}
+
+int efm_pred_forward(void* handle) {
+  Predictor* P = (Predictor*)handle;
+  EFM_REQUIRE(P, "pred_forward: null handle");
+  if (P->graph_state == 0) {
+    const char* e = getenv("EFM_PRED_GRAPH");
+    P->graph_state = -1;
+    if (!e || atoi(e) != 0) {
+      if (hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = pred_enqueue(P);
+        hipGraph_t g = nullptr;
+        const hipError_t ec = hipStreamEndCapture(P->stream, &g);
+        if (rc == EFM_OK && ec == hipSuccess && g && hipGraphInstantiate(&P->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+          P->graph = g;
+          P->graph_state = 1;
+        } else {
+          if (g) (void)hipGraphDestroy(g);
+          (void)hipGetLastError();  // capture unavailable: fall back to plain launches
+        }
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (P->graph_state == 1) {
+    if (hipGraphLaunch(P->graph_exec, P->stream) == hipSuccess) return EFM_OK;
+    efm::set_error("pred_forward: hipGraphLaunch failed");
+    return EFM_E_LAUNCH;
+  }
+  return pred_enqueue(P);
 }
 
 int efm_pred_get_output_shape(void* handle, uint32_t index, uint32_t** shape_data, uint32_t* shape_ndim) {

@@ -44,3 +44,51 @@ def test_predictor_matches_plan_forward(tmp_path):
     _lib.check(lib.efm_pred_free(h), "efm_pred_free")
     # a blob that is not an NDArray list
     assert lib.efm_pred_create(None, b"nonsense" * 8, 64, 0, 1, keys, indptr, shape, ctypes.byref(h)) == -1
+
+
+def test_predictor_single_image_graph_replay(tmp_path, monkeypatch):
+    """Deployment shape (Feature.hpp: one 1x128x128 face per call): the forward is captured into a HIP graph on the first call and
+    replayed; results are bit-identical to plain launches (EFM_PRED_GRAPH=0) call after call, and the replay is not slower."""
+    import time
+    from improving_face_recognition_performance_using_triplet_loss_amd import _lib, efm_symbol, mxio, synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.plan import Plan
+    batch, ch, image = 1, 1, 128
+    data = efm_symbol.G.Variable("data")
+    feat_sym, _ = efm_symbol.efm_feature(data)
+    plan = Plan([feat_sym], (2, ch, image, image))
+    flat = plan.new_flat()
+    plan.init_xavier(flat, 3)
+    params = {("arg:" + k): v.cpu().numpy() for k, v in plan.export_params(flat).items()}
+    params["arg:fc1_weight"] = params["arg:fc1_weight"].reshape(513, -1)
+    path = str(tmp_path / "EFM_RES.params")
+    mxio.save_params(path, params)
+    blob = open(path, "rb").read()
+    lib = _lib.load()
+    keys = (ctypes.c_char_p * 1)(b"data")
+    indptr = (ctypes.c_uint32 * 2)(0, 4)
+    shape = (ctypes.c_uint32 * 4)(batch, ch, image, image)
+    outs, times = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EFM_PRED_GRAPH", mode)
+        h = ctypes.c_void_p()
+        _lib.check(lib.efm_pred_create(None, blob, len(blob), 0, 1, keys, indptr, shape, ctypes.byref(h)), "efm_pred_create")
+        res = []
+        out = np.empty((batch, 342), np.float32)
+        for i in range(3):
+            xin = np.ascontiguousarray(synth.images(batch, ch, image, 50 + i).cpu().numpy())
+            _lib.check(lib.efm_pred_set_input(h, b"data", xin.ctypes.data_as(ctypes.c_void_p), xin.size), "set_input")
+            _lib.check(lib.efm_pred_forward(h), "forward")
+            _lib.check(lib.efm_pred_get_output(h, 0, out.ctypes.data_as(ctypes.c_void_p), out.size), "get_output")
+            res.append(out.copy())
+        t0 = time.perf_counter()
+        for _ in range(50):
+            _lib.check(lib.efm_pred_forward(h), "forward")
+        _lib.check(lib.efm_pred_get_output(h, 0, out.ctypes.data_as(ctypes.c_void_p), out.size), "get_output")
+        times[mode] = (time.perf_counter() - t0) / 50
+        outs[mode] = res
+        _lib.check(lib.efm_pred_free(h), "efm_pred_free")
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(outs["1"][0], outs["1"][1])          # the replay reads the new input, not a baked-in one
+    print("single-image forward: %.3f ms plain launches, %.3f ms graph replay" % (times["0"] * 1e3, times["1"] * 1e3))
+    assert times["1"] < 1.2 * times["0"]
