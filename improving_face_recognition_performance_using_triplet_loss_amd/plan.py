@@ -468,7 +468,7 @@ class Plan:
             main.wait_stream(side)
         return dx_input
 
-    def autotune(self, iters=3, verbose=False):
+    def autotune(self, iters=5, verbose=False):
         """Time the tiling candidates (64/128-pixel tiles x 1..3 channel blocks) of every plain convolution forward and
         data gradient at this plan's shapes and store the winners in the descriptors (results are bit-identical for every
         choice).  For the 3x3 / pad 1 layers the Winograd F(2x2,3x3) kernels (plain forward and data gradient) are timed
