@@ -63,13 +63,39 @@ class Dense(torch.nn.Module):
             ops.conv_pack_weights_into(self.desc(1), w.to(self.weight.device).reshape(self.units, self.in_units, 1, 1).contiguous(), self.weight)
 
 
+class BatchNorm(torch.nn.Module):
+    """Gluon nn.BatchNorm() on a (N, C) feature (ref: lightcnn.py:113-114,130): momentum 0.9, eps 1e-5, gamma ones / beta zeros.
+    Training mode normalises with the batch mean and the BIASED batch variance and tracks
+    `running = 0.9*running + 0.1*batch` with that same biased variance — MXNet's rule; torch.nn.BatchNorm1d tracks the unbiased
+    one, which would make the `running_var` written by save_parameters differ from the reference's by N/(N-1)."""
+
+    def __init__(self, in_channels, momentum=0.9, epsilon=1e-5):
+        super().__init__()
+        self.momentum, self.eps = momentum, epsilon
+        self.gamma = torch.nn.Parameter(torch.ones(in_channels))
+        self.beta = torch.nn.Parameter(torch.zeros(in_channels))
+        self.register_buffer("running_mean", torch.zeros(in_channels))
+        self.register_buffer("running_var", torch.ones(in_channels))
+
+    def forward(self, x):
+        if not self.training:
+            return torch.nn.functional.batch_norm(x, self.running_mean, self.running_var, self.gamma, self.beta, False, 0.0, self.eps)
+        with torch.no_grad():
+            mean = x.mean(dim=0)
+            var = x.var(dim=0, unbiased=False)
+            self.running_mean.mul_(self.momentum).add_(mean, alpha=1 - self.momentum)
+            self.running_var.mul_(self.momentum).add_(var, alpha=1 - self.momentum)
+        return torch.nn.functional.batch_norm(x, None, None, self.gamma, self.beta, True, 0.0, self.eps)
+
+
 class SymbolNet(torch.nn.Module):
     """A compiled `graph.Sym` network as a torch module (the role of gluon.SymbolBlock / HybridBlock.hybridize()).
     One flat nn.Parameter holds every weight in packed layout; plans are compiled per batch size on first use."""
 
-    def __init__(self, outputs, in_channels, image, device="cuda", seed=42, init="xavier"):
+    def __init__(self, outputs, in_channels, image, device="cuda", seed=42, init="xavier", fuse=None):
         super().__init__()
         self._outputs, self.in_channels, self.image = outputs, in_channels, image
+        self._fuse = fuse
         self._plans = {}
         self._dev = torch.device(device)
         p0 = self.plan(2)
@@ -81,7 +107,7 @@ class SymbolNet(torch.nn.Module):
     def plan(self, batch):
         p = self._plans.get(batch)
         if p is None:
-            p = self._plans[batch] = Plan(self._outputs, (batch, self.in_channels, self.image, self.image), self._dev)
+            p = self._plans[batch] = Plan(self._outputs, (batch, self.in_channels, self.image, self.image), self._dev, fuse=self._fuse)
         return p
 
     def forward(self, x):

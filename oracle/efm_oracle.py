@@ -532,3 +532,222 @@ def lfw_roc(thresholds, e1, e2, issame, nrof_folds=10, metric=0, subtract_mean=F
             tprs[f, ti], fprs[f, ti], _ = lfw_accuracy(t, dist[test], issame[test])
         acc[f] = lfw_accuracy(thresholds[best], dist[test], issame[test])[2]
     return tprs.mean(0), fprs.mean(0), acc
+
+
+# ----------------------------------------------------------------------------------------------
+# The Gluon variant: LightCNN_29 (lightcnn.py:6-133) and the train_efm.py step (train_efm.py:229-245).
+# This is the network entry point 1 actually trains: the two convolutions of a res_block are created ONCE
+# (lightcnn.py:47-48) and re-applied num_blocks times (:52-69), fc1 is Dense(1026) -> EFM -> 684-d (:111,123-128),
+# fc1_out = BatchNorm(feature) (:113-114,130), out = Dense(classes)(Dropout(.7)(feature)) (:116-118,131).
+# Every EFM here is `maximum(maximum(s0,s1), s2)` = ORDER_GROUP (:23-26,33-36,54-57,62-65,124-127).
+# Parameter names are this build's (g<k>_conv0/1, g<k>_res_conv0/1, fc1, batchnorm0_*, dense1_*); GLUON_STRUCT_NAMES maps them
+# to the structural names Block.save_parameters writes ("conv_net.2.conv_op_1.weight", ...) [MX-assumed (14)].
+# ----------------------------------------------------------------------------------------------
+LIGHTCNN29_BLOCKS = [1, 2, 3, 4]                      # lightcnn.py:77
+LIGHTCNN29_GROUPS = [(99, 198), (198, 387), (387, 261), (261, 261)]  # (num_filter, num_filter1) of efm(type 1), lightcnn.py:88,94,100,106
+
+
+def lightcnn29_layers(in_channels=1):
+    """[(name, cout, cin, k, pad)] — each SHARED convolution listed once."""
+    layers = [("g1_conv1", 99, in_channels, 5, 2)]    # efm(0, 99, 5x5, pad 2, type 0), lightcnn.py:82
+    c = 66
+    for gi, (nf, nf1) in enumerate(LIGHTCNN29_GROUPS):
+        g = gi + 2
+        layers.append(("g%d_res_conv0" % g, nf, 2 * c // 3, 3, 1))           # conv_op_1: channels=num_filter, lightcnn.py:47
+        layers.append(("g%d_res_conv1" % g, int(nf * (2. / 3.)), 2 * nf // 3, 3, 1))  # conv_op_2: int(num_filter*2/3), :45,48
+        layers.append(("g%d_conv0" % g, nf, c, 1, 0))                        # efm.conv_op_1 1x1, lightcnn.py:14
+        layers.append(("g%d_conv1" % g, nf1, 2 * nf // 3, 3, 1))             # efm.conv_op_2 kxk, lightcnn.py:15
+        c = 2 * nf1 // 3
+    return layers
+
+
+def lightcnn29_param_shapes(in_channels=1, image=128, classes=8398, fc_units=1026):
+    shapes = {}
+    for name, co, ci, k, _ in lightcnn29_layers(in_channels):
+        shapes[name + "_weight"] = (co, ci, k, k)
+        shapes[name + "_bias"] = (co,)
+    s = image
+    for _ in range(5):
+        s //= 2
+    shapes["fc1_weight"] = (fc_units, 174 * s * s)
+    shapes["fc1_bias"] = (fc_units,)
+    d = 2 * fc_units // 3
+    shapes["batchnorm0_gamma"] = (d,)
+    shapes["batchnorm0_beta"] = (d,)
+    shapes["dense1_weight"] = (classes, d)
+    shapes["dense1_bias"] = (classes,)
+    return shapes
+
+
+def gluon_struct_names():
+    """build name -> the key `net.save_parameters` writes for LightCNN_29 (Block._collect_params_with_prefix: attribute path,
+    Sequential children by index; lightcnn.py:79-118 gives the indices) [MX-assumed (14)]."""
+    m = {"g1_conv1": "conv_net.0.conv_op_2"}
+    for gi in range(4):
+        g, base = gi + 2, 2 + 3 * gi
+        m["g%d_res_conv0" % g] = "conv_net.%d.conv_op_1" % base
+        m["g%d_res_conv1" % g] = "conv_net.%d.conv_op_2" % base
+        m["g%d_conv0" % g] = "conv_net.%d.conv_op_1" % (base + 1)
+        m["g%d_conv1" % g] = "conv_net.%d.conv_op_2" % (base + 1)
+    m["fc1"] = "conv_net.15"
+    out = {}
+    for k, v in m.items():
+        out[k + "_weight"] = v + ".weight"
+        out[k + "_bias"] = v + ".bias"
+    for k in ("gamma", "beta", "running_mean", "running_var"):
+        out["batchnorm0_" + k] = "fc1.0." + k
+    out["dense1_weight"], out["dense1_bias"] = "fc2.1.weight", "fc2.1.bias"
+    return out
+
+
+def init_lightcnn29_params(shapes, seed=42):
+    p = init_params({k: v for k, v in shapes.items() if not k.startswith("batchnorm0_")}, seed)
+    p["batchnorm0_gamma"] = np.ones(shapes["batchnorm0_gamma"])   # Gluon BatchNorm: gamma ones, beta zeros
+    p["batchnorm0_beta"] = np.zeros(shapes["batchnorm0_beta"])
+    return p
+
+
+def batchnorm_train(x, gamma, beta, eps=1e-5):
+    """Gluon nn.BatchNorm() in training mode on a (N, C) matrix: batch mean, BIASED batch variance, eps 1e-5
+    [MX-assumed (13)]; returns (y, (xhat, inv_std, mean, var)).  ref: lightcnn.py:113-114,130."""
+    mean = x.mean(axis=0)
+    var = ((x - mean) ** 2).mean(axis=0)
+    inv = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * inv
+    return gamma * xhat + beta, (xhat, inv, mean, var)
+
+
+def batchnorm_train_bwd(cache, gamma, dy):
+    xhat, inv, _, _ = cache
+    n = dy.shape[0]
+    dxhat = dy * gamma
+    dx = inv / n * (n * dxhat - dxhat.sum(axis=0) - xhat * (dxhat * xhat).sum(axis=0))
+    return dx, (dy * xhat).sum(axis=0), dy.sum(axis=0)
+
+
+def batchnorm_running_update(running_mean, running_var, mean, var, momentum=0.9):
+    """MXNet: moving = moving*momentum + batch*(1-momentum), with the BIASED batch variance (torch tracks the unbiased one)."""
+    return running_mean * momentum + mean * (1 - momentum), running_var * momentum + var * (1 - momentum)
+
+
+def batchnorm_infer(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    return gamma * (x - running_mean) / np.sqrt(running_var + eps) + beta
+
+
+def lightcnn29_forward(params, x, tape=None, routing=None):
+    """x (N, C, H, W) -> 684-d EFM feature (the input of both heads).  With `tape`: records the backward closures
+    (`tape.ops`, `tape.grads`); gradients of the shared convolutions ACCUMULATE over their uses.
+    `routing` as in efm29_forward; keys: 'g1_efm', 'g1_pool', 'g<k>_res<i>_efm_in', 'g<k>_res<i>_efm', 'g<k>_efm0', 'g<k>_efm1',
+    'g<k>_pool', 'efm_fc1' = the INPUT of that EFM / pooling node."""
+    grads = {}
+
+    def R(key, val):
+        return np.asarray(routing[key]).reshape(val.shape) if routing is not None and key in routing else val
+
+    def push(fn):
+        if tape is not None:
+            tape.push(fn)
+
+    def conv(name, inp, pad):
+        w, b = params[name + "_weight"], params[name + "_bias"]
+        y = conv2d(inp, w, b, (pad, pad))
+
+        def bwd(dy, inp=inp, w=w):
+            dx, dw, db = conv2d_bwd(inp, w, dy, (pad, pad))
+            grads[name + "_weight"] = grads.get(name + "_weight", 0) + dw
+            grads[name + "_bias"] = grads.get(name + "_bias", 0) + db
+            return dx
+        return y, bwd
+
+    def efm_op(key, inp):
+        r = R(key, inp)
+        return mfm3(inp), (lambda dy: mfm3_bwd(r, dy, ORDER_GROUP))
+
+    def pool_op(key, inp):
+        r = R(key, inp)
+        return maxpool2(inp), (lambda dy: maxpool2_bwd(r, dy))
+
+    def chain(fns):
+        def bwd(g):
+            for f in reversed(fns):
+                g = f(g)
+            return g
+        return bwd
+
+    # group 1: efm(type 0) + pool  (lightcnn.py:82-83)
+    c, b1 = conv("g1_conv1", x, 2)
+    e, b2 = efm_op("g1_efm", c)
+    cur, b3 = pool_op("g1_pool", e)
+    push(chain([b1, b2, b3]))
+    for gi, nb in enumerate(LIGHTCNN29_BLOCKS):
+        g = gi + 2
+        for i in range(nb):                                   # res_block.hybrid_forward, lightcnn.py:50-71
+            e, f1 = efm_op("g%d_res%d_efm_in" % (g, i), cur)
+            c1, f2 = conv("g%d_res_conv0" % g, e, 1)
+            e2, f3 = efm_op("g%d_res%d_efm" % (g, i), c1)
+            c2, f4 = conv("g%d_res_conv1" % g, e2, 1)
+            cur = c2 + cur
+            inner = chain([f1, f2, f3, f4])
+            push(lambda gq, inner=inner: gq + inner(gq))
+        c0, f1 = conv("g%d_conv0" % g, cur, 0)                # efm(type 1), lightcnn.py:20-30
+        e0, f2 = efm_op("g%d_efm0" % g, c0)
+        c1, f3 = conv("g%d_conv1" % g, e0, 1)
+        e1, f4 = efm_op("g%d_efm1" % g, c1)
+        cur, f5 = pool_op("g%d_pool" % g, e1)
+        push(chain([f1, f2, f3, f4, f5]))
+    flat = cur
+    fc1 = fully_connected(flat, params["fc1_weight"], params["fc1_bias"])
+    feat, fe = efm_op("efm_fc1", fc1)
+
+    def fc_bwd(gq):
+        gq = fe(gq)
+        dx, dw, db = fully_connected_bwd(flat, params["fc1_weight"], gq)
+        grads["fc1_weight"], grads["fc1_bias"] = dw, db
+        return dx
+    push(fc_bwd)
+    if tape is not None:
+        tape.grads = grads
+    return feat
+
+
+def lightcnn29_heads(params, feat, dropout_mask=None, dropout_p=0.7):
+    """(out, fc1_out, cache) in training mode.  `dropout_mask` (same shape as feat, 0/1) makes Dropout(.7) replayable;
+    None = dropout off.  [MX-assumed (12)]: kept values are scaled by 1/(1-p)."""
+    fc1_out, bn = batchnorm_train(feat, params["batchnorm0_gamma"], params["batchnorm0_beta"])
+    d = feat if dropout_mask is None else feat * dropout_mask / (1.0 - dropout_p)
+    out = d @ params["dense1_weight"].T + params["dense1_bias"]
+    return out, fc1_out, (bn, d)
+
+
+def train_efm_step(params, x, labels, neg_idx, margin=0.2, alpha=0.1, dropout_mask=None, dropout_p=0.7, routing=None):
+    """One training step of train_efm.py:229-245 (with `nrom` read as `norm`): x = [B anchors ; B positives],
+    `labels` (2B,), `neg_idx` (B,) rows of the anchor half (detached).  Returns a dict with out (2B, classes), fc1_out (2B, 684),
+    TL / id / loss vectors (B,), `grads` (name -> d sum(loss) / d param, the ones-head-gradient backward [MX-assumed (9)]),
+    and the BatchNorm batch statistics."""
+    tape = Tape()
+    feat = lightcnn29_forward(params, x, tape, routing)
+    out, fc, (bn, dropped) = lightcnn29_heads(params, feat, dropout_mask, dropout_p)
+    b = x.shape[0] // 2
+    anc, pos = fc[:b], fc[b:2 * b]
+    neg = fc[neg_idx]                                            # copied through NumPy in the reference: no gradient
+    (ya, na), (yp, npos), (yn, _) = l2norm_frob(anc), l2norm_frob(pos), l2norm_frob(neg)
+    tl = triplet_loss(ya, yp, yn, margin)
+    idl = softmax_cross_entropy(out[:b], labels[:b])
+    loss = idl + alpha * tl
+    # backward of sum(loss)
+    da, dp, _ = triplet_loss_bwd(ya, yp, yn, tl, alpha * np.ones(b))
+    dfc = np.concatenate([l2norm_frob_bwd(ya, na, da), l2norm_frob_bwd(yp, npos, dp)], axis=0)
+    dout = np.zeros_like(out)
+    dout[:b] = softmax_cross_entropy_bwd(out[:b], labels[:b], np.ones(b))
+    grads = tape.grads
+    dfeat_bn, grads["batchnorm0_gamma"], grads["batchnorm0_beta"] = batchnorm_train_bwd(bn, params["batchnorm0_gamma"], dfc)
+    grads["dense1_weight"] = dout.T @ dropped
+    grads["dense1_bias"] = dout.sum(0)
+    dd = dout @ params["dense1_weight"]
+    if dropout_mask is not None:
+        dd = dd * dropout_mask / (1.0 - dropout_p)
+    g = dfeat_bn + dd
+    for fn in reversed(tape.ops):
+        g = fn(g)
+    return {"out": out, "fc1_out": fc, "feat": feat, "tl": tl, "id": idl, "loss": loss, "grads": grads,
+            "bn_mean": bn[2], "bn_var": bn[3]}

@@ -236,3 +236,37 @@ def efm29_forward_bf16(p, x):
         cur = _RoundBoth.apply(F.max_pool2d(mfm3(conv(cur, "conv%s" % layer, pad)), 2, 2))
     fc1 = _RoundBwd.apply(F.linear(cur.flatten(1), _RoundFwd.apply(p["fc1_weight"]), p["fc1_bias"]))
     return mfm3(fc1)
+
+
+# ---- the Gluon variant: LightCNN_29 (lightcnn.py:6-133) + the train_efm.py step (train_efm.py:229-245) -----------------------
+def lightcnn29_forward(p, x):
+    """(N,C,H,W) -> 684-d EFM feature.  The two convolutions of a res_block are the SAME tensors in every iteration
+    (lightcnn.py:47-48 created once, :52-69 re-applied) — autograd accumulates their gradient over the uses."""
+    cur = F.max_pool2d(mfm3(F.conv2d(x, p["g1_conv1_weight"], p["g1_conv1_bias"], padding=2)), 2, 2)      # lightcnn.py:82-83
+    for gi, nb in enumerate([1, 2, 3, 4]):                                                                 # lightcnn.py:77
+        g = gi + 2
+        for _ in range(nb):                                                                                # lightcnn.py:52-69
+            e = mfm3(cur)
+            c = F.conv2d(e, p["g%d_res_conv0_weight" % g], p["g%d_res_conv0_bias" % g], padding=1)
+            c = F.conv2d(mfm3(c), p["g%d_res_conv1_weight" % g], p["g%d_res_conv1_bias" % g], padding=1)
+            cur = c + cur
+        c = mfm3(F.conv2d(cur, p["g%d_conv0_weight" % g], p["g%d_conv0_bias" % g]))                        # lightcnn.py:20-28
+        c = mfm3(F.conv2d(c, p["g%d_conv1_weight" % g], p["g%d_conv1_bias" % g], padding=1))               # lightcnn.py:29-37
+        cur = F.max_pool2d(c, 2, 2)
+    return mfm3(F.linear(cur.flatten(1), p["fc1_weight"], p["fc1_bias"]))                                  # lightcnn.py:111,121-128
+
+
+def train_efm_step(p, x, labels, neg_idx, margin=0.2, alpha=0.1, dropout_mask=None, dropout_p=0.7):
+    """train_efm.py:229-245 with autograd: returns (out, fc1_out, TL, id_loss, loss) detached; gradients of sum(loss) land in .grad."""
+    feat = lightcnn29_forward(p, x)
+    fc = F.batch_norm(feat, None, None, p["batchnorm0_gamma"], p["batchnorm0_beta"], training=True, eps=1e-5)   # lightcnn.py:130
+    d = feat if dropout_mask is None else feat * dropout_mask / (1.0 - dropout_p)
+    out = F.linear(d, p["dense1_weight"], p["dense1_bias"])                                                   # lightcnn.py:131
+    b = x.shape[0] // 2
+    anc, pos = fc[:b], fc[b:2 * b]
+    neg = fc[neg_idx].detach()
+    tl = triplet_loss(anc / anc.norm(), pos / pos.norm(), neg / neg.norm(), margin)                            # train_efm.py:241
+    idl = F.cross_entropy(out[:b], labels[:b], reduction="none")                                               # train_efm.py:242
+    loss = idl + alpha * tl                                                                                    # train_efm.py:243
+    loss.sum().backward()
+    return out.detach(), fc.detach(), tl.detach(), idl.detach(), loss.detach()

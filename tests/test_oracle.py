@@ -287,3 +287,69 @@ def test_shard_gradients_sum_to_the_full_batch_gradient(nshards):
         total = g if total is None else {k: total[k] + g[k] for k in g}
     for k in full:
         assert np.abs(total[k] - full[k]).max() <= 1e-10 * (np.abs(full[k]).max() + 1e-30), k
+
+
+# ---- the Gluon variant: LightCNN_29 + the train_efm.py step (ref: lightcnn.py:6-133, train_efm.py:229-245) ------------------
+def test_lightcnn29_table_weight_sharing_and_gluon_keys():
+    layers = O.lightcnn29_layers(1)
+    assert len(layers) == 17 and layers[0] == ("g1_conv1", 99, 1, 5, 2)          # 29 applied convolutions, 17 distinct + Dense(1026)
+    assert dict((n, (co, ci)) for n, co, ci, _, _ in layers)["g4_res_conv0"] == (387, 172)
+    assert dict((n, (co, ci)) for n, co, ci, _, _ in layers)["g4_res_conv1"] == (258, 258)
+    sh = O.lightcnn29_param_shapes(1, 128, 8398)                                  # train_efm.py:154-159: 1x128x128, 8398 classes
+    assert sh["fc1_weight"] == (1026, 174 * 4 * 4) and sh["dense1_weight"] == (8398, 684) and sh["batchnorm0_gamma"] == (684,)
+    keys = O.gluon_struct_names()
+    assert keys["g1_conv1_weight"] == "conv_net.0.conv_op_2.weight" and keys["g5_res_conv1_bias"] == "conv_net.11.conv_op_2.bias"
+    assert keys["g5_conv0_weight"] == "conv_net.12.conv_op_1.weight" and keys["fc1_bias"] == "conv_net.15.bias"
+    assert keys["batchnorm0_running_var"] == "fc1.0.running_var" and keys["dense1_weight"] == "fc2.1.weight"
+    import lightcnn
+    assert lightcnn.gluon_param_names() == keys                                   # product and oracle derive the same table independently
+
+
+def test_batchnorm_kat():
+    x = np.array([[1.0, 10.0], [3.0, 10.0], [5.0, 16.0]])
+    y, (xhat, inv, mean, var) = O.batchnorm_train(x, np.array([2.0, 1.0]), np.array([0.5, 0.0]), eps=0.0)
+    assert np.allclose(mean, [3, 12]) and np.allclose(var, [8 / 3, 8])           # BIASED variance
+    assert np.allclose(y[:, 0], 2 * np.array([-2, 0, 2]) / math.sqrt(8 / 3) + 0.5)
+    rm, rv = O.batchnorm_running_update(np.zeros(2), np.ones(2), mean, var)
+    assert np.allclose(rm, [0.3, 1.2]) and np.allclose(rv, [0.9 + 0.8 / 3, 0.9 + 0.8])
+    # backward against finite differences
+    rng = np.random.default_rng(0)
+    x, g, b, dy = rng.normal(size=(6, 5)), rng.normal(size=5), rng.normal(size=5), rng.normal(size=(6, 5))
+    _, cache = O.batchnorm_train(x, g, b)
+    dx, dg, db = O.batchnorm_train_bwd(cache, g, dy)
+    f = lambda xx: (O.batchnorm_train(xx, g, b)[0] * dy).sum()  # noqa: E731
+    e = np.zeros_like(x)
+    e[2, 3] = 1e-6
+    assert abs((f(x + e) - f(x - e)) / 2e-6 - dx[2, 3]) < 1e-6
+    assert np.allclose(db, dy.sum(0))
+
+
+def test_lightcnn29_restatements_agree_and_reproduce_fixture():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_lightcnn29_golden as M
+    params, x, labels, neg = M.inputs()
+    rng = np.random.default_rng(3)
+    mask = (rng.uniform(size=(2 * M.BATCH, 684)) > 0.7).astype(np.float64)       # Dropout(.7) replayed through an explicit mask
+    for m in (None, mask):
+        r = O.train_efm_step(params, x, labels, neg, M.MARGIN, M.ALPHA, dropout_mask=m)
+        tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+        out, fc, tl, idl, loss = OT.train_efm_step(tp, torch.tensor(x), torch.tensor(labels), torch.tensor(neg.astype(np.int64)), M.MARGIN,
+                                                   M.ALPHA, dropout_mask=None if m is None else torch.tensor(m))
+        assert np.abs(out.numpy() - r["out"]).max() < 1e-10 and np.abs(loss.numpy() - r["loss"]).max() < 1e-10
+        for k, g in r["grads"].items():
+            assert np.abs(tp[k].grad.numpy() - g).max() <= 1e-9 * np.abs(g).max(), k
+        if m is None:
+            z = np.load(os.path.join(os.path.dirname(__file__), "golden", "lightcnn29_step.npz"))
+            assert np.allclose(r["loss"], z["loss"], rtol=1e-12) and np.allclose(r["fc1_out"], z["fc1_out"], rtol=1e-10, atol=1e-12)
+            assert np.allclose([np.abs(r["grads"][str(k)]).sum() for k in z["names"]], z["grad_abs_sums"], rtol=1e-10)
+    # a shared convolution's gradient is the SUM over its uses: perturbing the shared weight moves the loss by <grad, dw>
+    # (alpha = 0: the detached negatives make the triplet term's true derivative differ from its gradient BY DESIGN)
+    r = O.train_efm_step(params, x, labels, neg, M.MARGIN, 0.0)
+    dw = O.uniform_pm(params["g4_res_conv1_weight"].shape, 5, 1e-7)
+    p2 = dict(params)
+    p2["g4_res_conv1_weight"] = params["g4_res_conv1_weight"] + dw
+    r2 = O.train_efm_step(p2, x, labels, neg, M.MARGIN, 0.0)
+    pred = (r["grads"]["g4_res_conv1_weight"] * dw).sum()
+    assert abs((r2["loss"].sum() - r["loss"].sum()) - pred) < 1e-3 * abs(pred) + 1e-12

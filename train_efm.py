@@ -47,6 +47,18 @@ def acc(output, label):
     return (output.argmax(dim=1) == label.to(torch.int64)).float().mean().item()
 
 
+def forward_losses(net, data, label, neg_idx, batch_size, triplet_loss, softmax_cross_entropy, alpha, norm_mode="frobenius"):
+    """The body of the reference's `autograd.record()` block (ref: train_efm.py:229-243): data = [batch_size anchors ; batch_size
+    positives], negatives = rows `neg_idx` of fc, detached; loss_i = CE(output_i, label_i) + alpha * TripletLoss_i over the anchors.
+    Returns (loss (batch_size,), output, (anc, pos, neg), (TL_loss, id_loss))."""
+    output, fc = net(data)
+    anc, pos = fc[0:batch_size], fc[batch_size:batch_size * 2]
+    neg = F_.gather_negatives(fc, neg_idx)
+    TL_loss = triplet_loss(F_.l2_normalize(anc, norm_mode), F_.l2_normalize(pos, norm_mode), F_.l2_normalize(neg, norm_mode))
+    id_loss = softmax_cross_entropy(output[0:batch_size], label[0:batch_size].to(torch.int64))
+    return id_loss + alpha * TL_loss, output, (anc, pos, neg), (TL_loss, id_loss)
+
+
 def load_split(root, name, args, seed):
     path = os.path.join(root, name + ".npz")
     rec = os.path.join(root, name + ".rec")
@@ -115,13 +127,10 @@ def main(argv=None):
     def run(batch, train):
         data = batch.data[0].to(devs, non_blocking=True)
         label = batch.label[0].to(devs)
-        output, fc = net(data)
-        anc, pos = fc[0:batch_size], fc[batch_size:batch_size * 2]
         pool = batch_size if train else batch_size * 2
-        neg = F_.gather_negatives(fc, pick_negatives(label, batch_size, pool, rng).to(devs))
-        TL_loss = triplet_loss(F_.l2_normalize(anc, norm_mode), F_.l2_normalize(pos, norm_mode), F_.l2_normalize(neg, norm_mode))
-        id_loss = softmax_cross_entropy(output[0:batch_size], label[0:batch_size].to(torch.int64))
-        return id_loss + alpha * TL_loss, output, label, (anc, pos, neg)
+        neg_idx = pick_negatives(label, batch_size, pool, rng).to(devs)
+        loss, output, triplet, _ = forward_losses(net, data, label, neg_idx, batch_size, triplet_loss, softmax_cross_entropy, alpha, norm_mode)
+        return loss, output, label, triplet
 
     print("start training...", flush=True)
     for epoch in range(args.epochs):
