@@ -38,7 +38,28 @@ int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, in
 size_t bias_grad_ws_floats(const efm_conv_desc* d);
 int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s);
 
+// Raw-buffer offsets are 32 bits and the kernels use byte offset 2^31 (EFM_OOB) as the "always out of range" address that the
+// buffer range check turns into zeros (padding taps, tail rows): every activation tensor a convolution kernel addresses must
+// therefore stay BELOW 2^31 bytes, or the sentinel would land inside the tensor and read data instead of zeros.
+// esize = 4 (fp32, channels padded to 4) or 2 (bf16, channels padded to 8).  Returns nullptr when fine, else which tensor.
+inline const char* conv_tensor_too_large(const efm_conv_desc* d, size_t esize) {
+  const size_t cin = esize == 2 ? (size_t)((d->cin + 7) / 8 * 8) : (size_t)d->cin_p;
+  const size_t cout = esize == 2 ? (size_t)((d->cout + 7) / 8 * 8) : (size_t)d->cout_p;
+  if ((size_t)d->batch * d->hin * d->win * cin * esize >= 0x80000000ull) return "input";
+  if ((size_t)d->batch * d->hout * d->wout * cout * esize >= 0x80000000ull) return "output";
+  return nullptr;
+}
+
 }  // namespace efm
+
+#define EFM_REQUIRE_RANGE(d, esize, what)                                                                                  \
+  do {                                                                                                                     \
+    const char* which__ = efm::conv_tensor_too_large(d, esize);                                                            \
+    if (which__) {                                                                                                         \
+      efm::set_error("%s: the %s tensor reaches 2^31 bytes (32-bit buffer offsets; split the batch)", what, which__);      \
+      return EFM_E_INVALID;                                                                                                \
+    }                                                                                                                      \
+  } while (0)
 
 #define EFM_REQUIRE(cond, ...)        \
   do {                                \

@@ -1242,7 +1242,7 @@ int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, i
   d->tune_dgrad = 0;
   d->tune_wgrad = 0;
   EFM_REQUIRE((long)batch * hin * win * d->cin_p < (1L << 30) && (long)batch * d->hout * d->wout * d->cout_p < (1L << 30),
-              "conv_desc_init: tensor exceeds 2^30 elements (4 GiB buffer descriptors)");
+              "conv_desc_init: tensor exceeds 2^30 elements (the launches additionally require < 2^31 BYTES per tensor)");
   EFM_REQUIRE(d->k_pad < 65536 && d->dk_pad < 65536, "conv_desc_init: K = kh*kw*channels must stay below 65536");
   EFM_REQUIRE((long)batch * d->hout * d->wout < (1L << 23) && (long)batch * hin * win < (1L << 23),
               "conv_desc_init: batch*H*W must stay below 2^23 pixels");
@@ -1277,6 +1277,7 @@ int efm_conv_make_dgrad_weights(const efm_conv_desc* d, const float* w_packed, f
 int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias,
                  const float* residual, float* y, void* stream) {
   EFM_REQUIRE(d && x && w_packed && y, "conv_fwd: null argument");
+  EFM_REQUIRE_RANGE(d, 4, "conv_fwd");
   return run_fwd<float>(x, w_packed, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->hout, d->wout, d->cout_p,
                  d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, d->tune_fwd, (hipStream_t)stream);
 }
@@ -1286,6 +1287,7 @@ int efm_conv_mfm_supported(const efm_conv_desc* d) { return d != nullptr; }
 int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
                      unsigned char* route, int ways, int order, int pool, void* stream) {
   EFM_REQUIRE(d && x && w_packed && z && route, "conv_mfm_fwd: null argument");
+  EFM_REQUIRE_RANGE(d, 4, "conv_mfm_fwd");
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
   EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
@@ -1345,6 +1347,7 @@ int efm_mfm_pool_bwd(const unsigned char* route, const float* dz, float* dy, int
 int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_packed, const float* add,
                       float* dx, void* stream) {
   EFM_REQUIRE(d && dy && wd_packed && dx, "conv_bwd_data: null argument");
+  EFM_REQUIRE_RANGE(d, 4, "conv_bwd_data");
   // full correlation of dy with the flipped kernel: pad' = k - 1 - pad
   return run_fwd<float>(dy, wd_packed, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->hin, d->win, d->cin_p,
                  d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, d->tune_dgrad, (hipStream_t)stream);
@@ -1353,6 +1356,7 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
                         int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && x && dy && dw_packed, "conv_bwd_weight: null argument");
+  EFM_REQUIRE_RANGE(d, 4, "conv_bwd_weight");
   const WgradPlan pl = plan_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("conv_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
@@ -1423,12 +1427,14 @@ int efm_convb_cast_weights(const efm_conv_desc* d, const float* w_packed, uint16
 int efm_convb_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, const uint16_t* residual,
                   uint16_t* y, void* stream) {
   EFM_REQUIRE(d && x && wb && y, "convb_fwd: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_fwd");
   return run_fwd<__bf16>(x, wb, bias, residual, y, d->batch, d->hin, d->win, pad8(d->cin), d->hout, d->wout, pad8(d->cout), d->kh, d->kw,
                          d->pad_h, d->pad_w, d->n_pad16, pad32(d->kh * d->kw * pad8(d->cin)), d->tune_fwd, (hipStream_t)stream);
 }
 
 int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_t* wdb, const uint16_t* add, uint16_t* dx, void* stream) {
   EFM_REQUIRE(d && dy && wdb && dx, "convb_bwd_data: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_bwd_data");
   return run_fwd<__bf16>(dy, wdb, nullptr, add, dx, d->batch, d->hout, d->wout, pad8(d->cout), d->hin, d->win, pad8(d->cin), d->kh, d->kw,
                          d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, pad32(d->kh * d->kw * pad8(d->cout)), d->tune_dgrad,
                          (hipStream_t)stream);
@@ -1437,6 +1443,7 @@ int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_
 int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, void* z, unsigned char* route,
                       int ways, int order, int pool, int out_f32, void* stream) {
   EFM_REQUIRE(d && x && wb && z && route, "convb_mfm_fwd: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_mfm_fwd");
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "convb_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "convb_mfm_fwd: bad order %d", order);
   const int cs_all = d->cout / ways;
@@ -1500,6 +1507,7 @@ int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f3
 int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && x && dy && dw_packed, "convb_bwd_weight: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_bwd_weight");
   const WgradBPlan pl = plan_wgradb(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("convb_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));

@@ -889,6 +889,7 @@ int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u,
 int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z, unsigned char* route, int ways,
                      int order, int pool, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && x && u && z && route, "wino_mfm_fwd: unsupported descriptor or null argument");
+  EFM_REQUIRE_RANGE(d, 4, "wino_mfm_fwd");
   EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "wino_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
   EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "wino_mfm_fwd: bad order %d", order);
   EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "wino_mfm_fwd: pooling needs a map of at least 2x2");
@@ -898,11 +899,13 @@ int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, con
 
 int efm_wino_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, const float* residual, float* y, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && x && u && y, "wino_fwd: unsupported descriptor or null argument");
+  EFM_REQUIRE_RANGE(d, 4, "wino_fwd");
   return run_wino(x, u, bias, residual, y, d->batch, d->hin, d->win, d->cin_p, d->cout, d->cout_p, d->tune_fwd, (hipStream_t)stream);
 }
 
 int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dgrad, const float* add, float* dx, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && dy && u_dgrad && dx, "wino_bwd_data: unsupported descriptor or null argument");
+  EFM_REQUIRE_RANGE(d, 4, "wino_bwd_data");
   return run_wino(dy, u_dgrad, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->cin, d->cin_p, d->tune_dgrad, (hipStream_t)stream);
 }
 
@@ -911,6 +914,7 @@ size_t efm_wino_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wino
 int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias, int accumulate,
                         void* workspace, size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(efm_wino_supported(d) && x && dy && dw_packed, "wino_bwd_weight: unsupported descriptor or null argument");
+  EFM_REQUIRE_RANGE(d, 4, "wino_bwd_weight");
   const WinoWPlan pl = plan_wino_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("wino_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));

@@ -53,3 +53,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     with pytest.raises(_lib.EfmError) as e:
         _lib.load()
     assert "no CPU fallback" in str(e.value).replace("There is no", "no")
+
+
+def test_tensors_at_or_above_2_gib_are_refused_before_any_launch():
+    """The kernels address activations through 32-bit raw-buffer offsets and use byte offset 2^31 as the always-out-of-range
+    sentinel for padding taps (csrc/efm_conv.hip EFM_OOB): a tensor that reaches 2^31 bytes would make the sentinel a valid
+    address, so every convolution entry point refuses it (no GPU is touched: the check precedes the launch).
+    fp32 LightCNN-9 conv1 at B = 512: 512 x 112 x 112 x 96 x 4 B = 2.47 GB of dy."""
+    lib = _lib.load()
+    big = _lib.conv_desc(512, 112, 112, 3, 96, 5, 5, 2, 2)           # descriptor itself is legal (bf16 activations fit)
+    fake = ctypes.c_void_p(4096)                                       # never dereferenced
+    for call in (lambda: lib.efm_conv_fwd(ctypes.byref(big), fake, fake, None, None, fake, None),
+                 lambda: lib.efm_conv_mfm_fwd(ctypes.byref(big), fake, fake, None, fake, fake, 2, 0, 1, None),
+                 lambda: lib.efm_conv_bwd_data(ctypes.byref(big), fake, fake, None, fake, None),
+                 lambda: lib.efm_conv_bwd_weight(ctypes.byref(big), fake, fake, fake, None, 0, fake, 1 << 40, None)):
+        assert call() == -1
+        assert b"2^31 bytes" in lib.efm_last_error_string() and b"output tensor" in lib.efm_last_error_string()
+    big3 = _lib.conv_desc(512, 112, 112, 96, 96, 3, 3, 1, 1)
+    assert lib.efm_wino_fwd(ctypes.byref(big3), fake, fake, None, None, fake, None) == -1
+    assert b"input tensor" in lib.efm_last_error_string()
+    ok = _lib.conv_desc(256, 112, 112, 3, 99, 5, 5, 2, 2)            # BASELINE configs[1] conv1: 1.28 GB, below the limit
+    from improving_face_recognition_performance_using_triplet_loss_amd.build import CSRC
+    assert "conv_tensor_too_large" in open(os.path.join(CSRC, "efm_common.h")).read()
+    assert ok.batch * ok.hout * ok.wout * ok.cout_p * 4 < 2 ** 31
