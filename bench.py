@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 (lightcnn9 only) = BASELINE configs[2]: bf16 operands / activations, fp32 accumulate + master weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32, help="images of the CPU-baseline sample (~15 s of host work)")
+    ap.add_argument("--cpu-batch", type=int, default=64, help="images of the CPU-baseline sample: BASELINE configs[0] = 64 faces (~30 s of host work)")
     return ap.parse_args()
 
 
@@ -94,7 +94,8 @@ def dominant_kernel_roofline(trainer, torch, iters=5):
 
 def cpu_baseline(batch, image, torch):
     """The CPU restatement of the reference graph (oracle/efm_oracle_torch.py, torch-CPU fp32 / oneDNN) timed on this
-    box's host cores on a bounded sample: `batch` images per step, 1 warm-up + 2 timed steps."""
+    box's host cores on a bounded sample: BASELINE configs[0] — `batch` = 64 images per step (32 triplets), fwd + bwd + SGD, ID head
+    off — 1 warm-up + 3 timed steps, median (SURVEY.md §8d asks for 3 + 10; bounded here so that the default run stays within minutes)."""
     from oracle import efm_oracle as O
     from oracle import efm_oracle_torch as OT
     threads = torch.get_num_threads()
@@ -112,7 +113,15 @@ def cpu_baseline(batch, image, torch):
     h = batch // 2
     neg = (torch.arange(h) + 1) % h
     times = []
-    for i in range(3):
+    cpu_model = "unknown CPU"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    for i in range(4):
         for t in list(p.values()) + [wh]:
             t.grad = None
         t0 = time.perf_counter()
@@ -124,13 +133,34 @@ def cpu_baseline(batch, image, torch):
         if i > 0:
             times.append(dt)
     dt = sorted(times)[len(times) // 2]
-    return {"value": round(h / dt, 3), "unit": "triplets/s", "cores": threads, "kind": "port",
+    return {"value": round(h / dt, 3), "unit": "triplets/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
+            "logical_cpus": os.cpu_count(),
             "sample": "torch-CPU fp32 restatement (oracle/efm_oracle_torch.py) of the same EFM-29 step on %d images of "
-                      "%dx%dx3 (= %d triplets), 1 warm-up + 2 timed steps, median %.2f s/step" % (batch, image, image, h, dt)}
+                      "%dx%dx3 (= %d triplets; BASELINE configs[0]), 1 warm-up + %d timed steps, median %.2f s/step, %d torch threads on %s"
+                      % (batch, image, image, h, len(times), dt, threads, cpu_model)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly (no torchrun environment): start the N ranks as a CHILD process — one process per
+    GPU, `torch.distributed.run`, rendezvous on 127.0.0.1 — and exit with its return code.  Nothing in this process has touched the
+    GPU yet (torch is not even imported), so no program is replaced after GPU initialisation."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -175,9 +205,18 @@ def main():
         batches = [(synth.images(args.batch, 3, args.image, 1234 + 1000 * rank + s, device), None) for s in range(2)]
         triplets_per_step = args.batch
     else:
+        # kernel selection: the COMMITTED table for this configuration (what tests/test_tuned_gpu.py exercises at full size) unless
+        # EFM_TUNING_FILE names another one or EFM_AUTOTUNE=live asks for a fresh timing run; EFM_AUTOTUNE=0 = heuristics only
+        from improving_face_recognition_performance_using_triplet_loss_amd import tuning as tuning_mod
+        mode = os.environ.get("EFM_AUTOTUNE", "1")
+        table, tuning_src = (None, None)
+        if args.dtype == "f32" and mode not in ("0", "live"):
+            table, tuning_src = tuning_mod.load("efm", args.batch, args.image, "f32", file=os.environ.get("EFM_TUNING_FILE"))
         tr = TripletTrainer(args.batch, image=args.image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
-                            n_buckets=int(os.environ.get("EFM_BUCKETS", "6")), dtype=args.dtype,
-                            autotune=args.dtype == "f32" and os.environ.get("EFM_AUTOTUNE", "1") != "0")
+                            n_buckets=int(os.environ.get("EFM_BUCKETS", "6")), dtype=args.dtype, tuning=table,
+                            autotune=args.dtype == "f32" and mode != "0")
+        if table is None:
+            tuning_src = "live autotune" if (args.dtype == "f32" and mode != "0") else "heuristics"
         labels = synth.parity_labels(args.batch, rank=rank)
         batches = []
         for s in range(2):  # resident synthetic batches, seed = 1234 + 1000*rank + step
@@ -238,6 +277,10 @@ def main():
             out["step_mfma_roofline_frac"] = round(images / world * flop_per_image / (PEAK_BF16_MFMA_TFLOPS * 1e12), 4)
         else:
             out["roofline"] = dominant_kernel_roofline(tr, torch)
+            # the kernel selection that was timed, as data: feed it back with EFM_TUNING_FILE=<json with {"table": ...}> to reproduce
+            out["tuning"] = {"source": tuning_src, "table": {k: [v["tune_fwd"], v["tune_dgrad"], v["tune_wgrad"], int(v["wino_fwd"]), int(v["wino_dgrad"])]
+                                                               for k, v in tr.plan.tuning_table().items()},
+                             "columns": ["tune_fwd", "tune_dgrad", "tune_wgrad", "wino_fwd", "wino_dgrad"]}
         if world == 1 and not args.no_cpu_baseline and args.workload == "efm" and args.dtype == "f32":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.image, torch)
         print(json.dumps(out), flush=True)

@@ -27,6 +27,7 @@ class BucketReducer:
         self._pending = None
         self._handles = []
         self.launch_order = []
+        self.last_launch_order = []
         self.reset()
 
     @staticmethod
@@ -76,4 +77,5 @@ class BucketReducer:
             raise RuntimeError("buckets %s never became ready" % missing)
         for h in self._handles:
             h.wait()
+        self.last_launch_order = list(self.launch_order)
         self.reset()

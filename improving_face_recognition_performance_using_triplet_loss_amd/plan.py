@@ -587,7 +587,42 @@ class Plan:
             seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad, d.tune_wgrad)
         if verbose:
             print("[efm autotune]", {k: v for k, v in chosen.items() if v})
+        self.chosen = chosen
         return chosen
+
+    # The kernel selection as data: what autotune() decided can be written out, committed and applied again, so that the
+    # selection a benchmark times is exactly the selection the parity tests exercise (timing-based choices differ run to run).
+    def tuning_table(self):
+        """{layer name: {tune_fwd, tune_dgrad, tune_wgrad, wino_fwd, wino_dgrad}} of every convolution step (JSON-able)."""
+        table = collections.OrderedDict()
+        for st in self.steps:
+            if st.op == "conv":
+                d = st.desc
+                table[st.pname] = {"tune_fwd": int(d.tune_fwd), "tune_dgrad": int(d.tune_dgrad), "tune_wgrad": int(d.tune_wgrad),
+                                   "wino_fwd": bool(getattr(st, "wino_fwd", False)), "wino_dgrad": bool(getattr(st, "wino_dgrad", False))}
+        return table
+
+    def apply_tuning(self, table):
+        """Install a table written by tuning_table() (layers it does not name keep the heuristics).  Every choice is a valid
+        kernel for every batch size; the Winograd flags are honoured only where the Winograd kernels apply."""
+        n = 0
+        for st in self.steps:
+            if st.op != "conv" or st.pname not in table:
+                continue
+            t, d = table[st.pname], st.desc
+            if isinstance(t, (list, tuple)):  # the compact row form bench.py prints
+                t = dict(zip(("tune_fwd", "tune_dgrad", "tune_wgrad", "wino_fwd", "wino_dgrad"), t))
+            wino_ok = self.dtype == "f32" and ops.wino_supported(d)
+            st.wino_fwd = bool(t.get("wino_fwd")) and wino_ok
+            st.wino_dgrad = bool(t.get("wino_dgrad")) and wino_ok
+            d.tune_fwd = int(t.get("tune_fwd", 0)) if (st.wino_fwd or not t.get("wino_fwd")) else 0
+            d.tune_dgrad = int(t.get("tune_dgrad", 0)) if (st.wino_dgrad or not t.get("wino_dgrad")) else 0
+            d.tune_wgrad = int(t.get("tune_wgrad", 0))
+            for attr in ("u_fwd", "u_dgrad"):  # U's layout follows the Winograd variant
+                if hasattr(st, attr):
+                    delattr(st, attr)
+            n += 1
+        return n
 
     def _side_stream(self):
         if self._side is None:

@@ -15,14 +15,18 @@ from .plan import Plan
 class TripletTrainer:
     def __init__(self, batch, image=112, in_channels=3, embed_dim=128, margin=0.2, optimizer="sgd", lr=2.4e-4, wd=1e-5,
                  device="cuda", seed=42, process_group=None, n_buckets=6, normalize=True, outputs=None, fuse=None,
-                 autotune=False, dtype="f32"):
+                 autotune=False, dtype="f32", tuning=None):
+        """tuning: a kernel-selection table (plan.tuning_table() / tuning.load()) applied instead of timing candidates — the
+        reproducible form of `autotune=True`."""
         self.batch, self.half = batch, batch // 2
         self.margin, self.lr, self.wd = margin, lr, wd
         self.optimizer = optimizer
         self.device = torch.device(device)
         self.plan = Plan(outputs if outputs is not None else efm_symbol.embedding_net(embed_dim, normalize),
                          (batch, in_channels, image, image), device, fuse=fuse, dtype=dtype)
-        if autotune:
+        if tuning is not None:
+            self.plan.apply_tuning(tuning)
+        elif autotune:
             self.plan.autotune()
         self.flat = self.plan.new_flat()
         self.plan.init_xavier(self.flat, seed)

@@ -1,0 +1,73 @@
+"""The data-parallel path with more than one rank actually running (ref: mutli_gpu_v3.py:117,153-162)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    return dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+
+
+def test_two_rank_step_equals_single_process_double_batch(tmp_path):
+    """Two ranks x 8 images (own anchors, positives, LOCAL negatives) for two SGD steps == one process stepping the same 16 images
+    with the same triplets: the gradient exchange is a plain SUM launched bucket by bucket from backward (late layers first), the
+    mean is the optimiser's rescale = 1/(global anchors).  Both ranks end with bit-identical parameters; the 2-rank and the
+    1-process UPDATES agree to 1e-4 after one step."""
+    batch, image, steps = 8, 32, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "dp_worker.py"), str(tmp_path), str(batch), str(image), str(steps)]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ranks = [torch.load(str(tmp_path / ("rank%d.pt" % k)), weights_only=True) for k in range(2)]
+    assert torch.equal(ranks[0]["flat"], ranks[1]["flat"]) and torch.equal(ranks[0]["grad"], ranks[1]["grad"])
+    for k in range(2):
+        assert ranks[k]["order"] == sorted(ranks[k]["order"], reverse=True) and len(ranks[k]["order"]) == ranks[k]["nbuckets"] > 1
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dp_worker import shard_inputs
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    (x0, n0), (x1, n1) = shard_inputs(0, batch, image), shard_inputs(1, batch, image)
+    h = batch // 2
+    x = torch.cat([x0[:h], x1[:h], x0[h:], x1[h:]])                     # [anchors r0, anchors r1 ; positives r0, positives r1]
+    neg = torch.cat([n0, n1 + h]).to(torch.int32)
+    big = TripletTrainer(2 * batch, image=image, seed=3, optimizer="sgd", lr=0.05, wd=1e-5)
+    init = big.flat.clone()
+    losses, errs = [], []
+    for k in range(steps):
+        losses.append(big.step(x, neg).clone())
+        upd_big = (big.flat - init).cpu()
+        upd_dp = ranks[0]["flats"][k] - init.cpu()
+        errs.append(float((upd_dp - upd_big).abs().max() / upd_big.abs().max()))
+    assert torch.equal(losses[0].cpu(), torch.cat([ranks[0]["loss"][0], ranks[1]["loss"][0]]))   # step 1 forward: identical weights
+    print("2-rank vs single-process update: rel err after step 1 %.2e, after step 2 %.2e" % (errs[0], errs[1]))
+    assert errs[0] < 1e-4, errs      # one step: the summation order of the split weight gradient is the only difference
+    assert errs[1] < 2e-3, errs      # two steps: last-bit weight differences move a few max/min/pool routes of the second forward
+
+
+def test_bench_gpus2_self_starts_and_reports_one_line(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment starts its own ranks as a child process (both on the one card of this box,
+    gloo instead of RCCL) and rank 0 prints the single JSON line with n_gpus = 2, whole-job throughput, scaling 'weak'."""
+    env = dict(_env(), EFM_BENCH_ONE_DEVICE="1", EFM_DIST_BACKEND="gloo", EFM_AUTOTUNE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--image", "32"], env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "triplets/s" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2"
