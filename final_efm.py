@@ -55,7 +55,7 @@ def main(argv=None):
         if not args.synthetic and os.path.exists(rec):
             it = mxio.ImageRecordIter(path_imgrec=rec, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True, data_shape=shape,
                                       batch_size=batch_size, seed=seed)
-            return it, (len(open(lst).readlines()) if os.path.exists(lst) else len(it.data_arr))
+            return it, (len(open(lst).readlines()) if os.path.exists(lst) else len(it))
         if not args.synthetic:
             raise SystemExit("no %s found — pass --synthetic N" % rec)
         return synthetic_source(n, shape, max(n // 4, 2), seed, batch_size), n

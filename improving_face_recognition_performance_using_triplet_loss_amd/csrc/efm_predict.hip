@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "efm_common.h"
+#include "../../include/c_predict_api.h"
 
 namespace {
 
@@ -316,5 +317,55 @@ int efm_pred_free(void* handle) {
   delete (Predictor*)handle;
   return EFM_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// MXNet c_predict_api names and signatures (include/c_predict_api.h) over the predictor above: the symbols Feature.hpp links to.
+// ------------------------------------------------------------------------------------------------------------------
+const char* MXGetLastError(void) { return efm_last_error_string(); }
+
+int MXPredCreatePartialOut(const char* symbol_json_str, const void* param_bytes, int param_size, int dev_type, int dev_id,
+                           mx_uint num_input_nodes, const char** input_keys, const mx_uint* input_shape_indptr,
+                           const mx_uint* input_shape_data, mx_uint num_output_nodes, const char** output_keys, PredictorHandle* out) {
+  if (dev_type != 2) {  // 1 = cpu, 2 = gpu (Feature.hpp:165): this library has no CPU path
+    efm::set_error("MXPredCreate: dev_type %d refused (2 = gpu is the only device type)", dev_type);
+    return -1;
+  }
+  if (num_output_nodes > 1 || (num_output_nodes == 1 && (!output_keys || !output_keys[0]))) {
+    efm::set_error("MXPredCreatePartialOut: one output node (the 342-d feature) is available, %u requested", num_output_nodes);
+    return -1;
+  }
+  if (num_output_nodes == 1) {
+    const std::string k(output_keys[0]);
+    if (k != "concat29" && k != "concat29_output") {  // MXNet appends "_output" to the key itself
+      efm::set_error("MXPredCreatePartialOut: unknown output node '%s' (the feature node is 'concat29')", k.c_str());
+      return -1;
+    }
+  }
+  return efm_pred_create(symbol_json_str, param_bytes, param_size, dev_id, num_input_nodes, input_keys, input_shape_indptr, input_shape_data,
+                         out) == EFM_OK ? 0 : -1;
+}
+
+int MXPredCreate(const char* symbol_json_str, const void* param_bytes, int param_size, int dev_type, int dev_id, mx_uint num_input_nodes,
+                 const char** input_keys, const mx_uint* input_shape_indptr, const mx_uint* input_shape_data, PredictorHandle* out) {
+  return MXPredCreatePartialOut(symbol_json_str, param_bytes, param_size, dev_type, dev_id, num_input_nodes, input_keys, input_shape_indptr,
+                                input_shape_data, 0, nullptr, out);
+}
+
+int MXPredGetOutputShape(PredictorHandle handle, mx_uint index, mx_uint** shape_data, mx_uint* shape_ndim) {
+  return efm_pred_get_output_shape(handle, index, shape_data, shape_ndim) == EFM_OK ? 0 : -1;
+}
+
+int MXPredSetInput(PredictorHandle handle, const char* key, const mx_float* data, mx_uint size) {
+  return efm_pred_set_input(handle, key, data, size) == EFM_OK ? 0 : -1;
+}
+
+int MXPredForward(PredictorHandle handle) { return efm_pred_forward(handle) == EFM_OK ? 0 : -1; }
+
+int MXPredGetOutput(PredictorHandle handle, mx_uint index, mx_float* data, mx_uint size) {
+  return efm_pred_get_output(handle, index, data, size) == EFM_OK ? 0 : -1;
+}
+
+int MXPredFree(PredictorHandle handle) { return efm_pred_free(handle) == EFM_OK ? 0 : -1; }
 
 }  // extern "C"

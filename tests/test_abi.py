@@ -76,3 +76,31 @@ def test_tensors_at_or_above_2_gib_are_refused_before_any_launch():
     from improving_face_recognition_performance_using_triplet_loss_amd.build import CSRC
     assert "conv_tensor_too_large" in open(os.path.join(CSRC, "efm_common.h")).read()
     assert ok.batch * ok.hout * ok.wout * ok.cout_p * 4 < 2 ** 31
+
+
+def test_c_predict_api_symbols_and_feature_hpp_consumer_link(tmp_path):
+    """include/c_predict_api.h: the MXNet entry points the reference's deployment code calls (Feature.hpp:163-205) are exported
+    with MXNet's names, and a consumer written against that header alone LINKS with plain g++ (the run is a GPU test)."""
+    import shutil
+    import subprocess
+    text = open(os.path.join(ROOT, "include", "c_predict_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(MX[A-Za-z]+)\s*\(", text)))
+    assert names == sorted(["MXGetLastError", "MXPredCreate", "MXPredCreatePartialOut", "MXPredGetOutputShape", "MXPredSetInput",
+                            "MXPredForward", "MXPredGetOutput", "MXPredFree"])
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    # error convention without a GPU: the CPU device type is refused with -1 and a message
+    lib.MXGetLastError.restype = ctypes.c_char_p
+    h = ctypes.c_void_p()
+    assert lib.MXPredCreate(b"{}", b"x", 1, 1, 0, 1, None, None, None, ctypes.byref(h)) == -1
+    assert b"dev_type 1 refused" in lib.MXGetLastError()
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    pkg = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run([gxx, "-std=c++11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "feature_consumer.cpp"),
+                        "-L", pkg, "-lefm_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(tmp_path / "feature_consumer")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -77,3 +77,77 @@ def test_symbol_json_round_trip_efm29_and_mfm2(tmp_path):
     path = str(tmp_path / "efm-symbol.json")
     heads = mxio.load_symbol(path, outputs=["fc2_output"])
     assert heads[0].op == "fc" and heads[0].name == "fc2"
+
+
+def test_params_file_byte_level_known_answer(tmp_path):
+    """A .params file assembled BY HAND from MXNet 1.x's published layout (src/ndarray/ndarray.cc: NDArray::Save list header
+    kMXAPINDArrayListMagic = 0x112, reserved 0, count; per array NDARRAY_V2_MAGIC 0xF993FAC9, storage type 0, TShape (uint32 ndim +
+    int64 dims), Context {dev_type int32 = 1 cpu, dev_id int32}, type flag int32 (0 = float32), raw data; then the name list with
+    uint64 lengths) — not produced by this package's writer — must load, and the writer must reproduce it byte for byte.
+    Spec-pinned, not MXNet-pinned: no MXNet-written file exists in the reference or this image."""
+    blob = bytes.fromhex(
+        "1201000000000000" "0000000000000000" "0200000000000000"                 # list magic 0x112, reserved, 2 arrays
+        "c9fa93f9" "00000000" "02000000" "0200000000000000" "0300000000000000"   # V2 magic, stype 0, ndim 2, shape (2, 3)
+        "01000000" "00000000" "00000000"                                         # Context cpu(0), type flag 0 = float32
+        "0000803f" "00000040" "00004040" "00008040" "0000a040" "0000c040"        # 1 2 3 4 5 6
+        "c9fa93f9" "00000000" "01000000" "0200000000000000"                      # V2 magic, stype 0, ndim 1, shape (2,)
+        "01000000" "00000000" "00000000"
+        "000000bf" "00002041"                                                    # -0.5, 10
+        "0200000000000000"                                                       # 2 names
+        "0d00000000000000") + b"arg:fc_weight" + bytes.fromhex("0b00000000000000") + b"aux:bn_mean"
+    path = tmp_path / "hand-0001.params"
+    path.write_bytes(blob)
+    got = mxio.load_params(str(path))
+    assert list(got) == ["fc_weight", "bn_mean"]
+    assert got["fc_weight"].dtype == np.float32 and np.array_equal(got["fc_weight"], [[1, 2, 3], [4, 5, 6]])
+    assert np.array_equal(got["bn_mean"], [-0.5, 10.0])
+    raw = mxio.load_params(str(path), strip_prefix=False)
+    assert list(raw) == ["arg:fc_weight", "aux:bn_mean"]
+    out = tmp_path / "rewritten.params"
+    mxio.save_params(str(out), raw)
+    assert out.read_bytes() == blob
+
+
+def test_recordio_byte_level_known_answer(tmp_path):
+    """One RecordIO record assembled by hand from dmlc-core's recordio.h (uint32 kMagic 0xced7230a, uint32 lrecord = cflag << 29 |
+    length, payload, zero padding to 4 bytes) holding an mx.recordio IRHeader ('IfQQ': flag 0, label 7.0, id 42, id2 0) and a
+    payload tail; plus a record split into two parts at an embedded magic word (cflag 1 then 3), which readers must re-join with
+    the magic re-inserted."""
+    head = bytes.fromhex("00000000" "0000e040" "2a00000000000000" "0000000000000000")          # IRHeader(0, 7.0, 42, 0)
+    rec1 = bytes.fromhex("0a23d7ce" "1b000000") + head + b"abc" + b"\x00"                       # length 27 -> 1 pad byte
+    magic = bytes.fromhex("0a23d7ce")
+    part_a, part_b = b"1234", b"5678xy"
+    rec2 = magic + (1 << 29 | len(part_a)).to_bytes(4, "little") + part_a + magic + (3 << 29 | len(part_b)).to_bytes(4, "little") + part_b + b"\x00\x00"
+    path = tmp_path / "hand.rec"
+    path.write_bytes(rec1 + rec2)
+    recs = list(mxio.read_records(str(path)))
+    assert recs == [head + b"abc", part_a + magic + part_b]
+    import struct
+    assert struct.unpack_from("<IfQQ", recs[0]) == (0, 7.0, 42, 0)
+    idx = mxio.index_records(str(path))
+    assert idx == [(0, 27), (36, -1)]
+    with open(path, "rb") as f:
+        assert [mxio.read_record_at(f, *e) for e in idx] == recs
+    # the writer emits the single-part form of the first record byte for byte
+    out = tmp_path / "w.rec"
+    mxio.write_records(str(out), [head + b"abc"])
+    assert out.read_bytes() == rec1
+
+
+def test_image_record_iter_streams_and_shards(tmp_path):
+    """ImageRecordIter keeps an index, not pixels; `part_index` / `num_parts` (MXNet's parameters) give data-parallel ranks disjoint
+    shares that together cover the file once; crops / mirrors / order are redrawn every epoch."""
+    rng = np.random.default_rng(2)
+    imgs = [rng.integers(0, 256, size=(20, 20), dtype=np.uint8) for _ in range(10)]
+    path = str(tmp_path / "d.rec")
+    mxio.write_records(path, [mxio.pack_img(float(i), i, im) for i, im in enumerate(imgs)])
+    parts = [mxio.ImageRecordIter(path, (1, 20, 20), batch_size=1, part_index=k, num_parts=3) for k in range(3)]
+    seen = [[int(b.label[0][0]) for b in p] for p in parts]
+    assert sorted(sum(seen, [])) == list(range(10)) and [len(s) for s in seen] == [3, 3, 4]
+    assert all(p.num_total == 10 for p in parts) and not hasattr(parts[0], "data_arr")
+    it = mxio.ImageRecordIter(path, (1, 16, 16), batch_size=5, rand_crop=True, rand_mirror=True, shuffle=True, seed=1)
+    e1 = [b.label[0].tolist() for b in it]
+    e2 = [b.label[0].tolist() for b in it]
+    assert sorted(sum(e1, [])) == sorted(sum(e2, [])) == [float(i) for i in range(10)] and e1 != e2
+    full = next(iter(mxio.ImageRecordIter(path, (1, 20, 20), batch_size=10, scale=1.0 / 255)))
+    assert np.allclose(full.data[0][3, 0].numpy() * 255, imgs[3])

@@ -67,7 +67,7 @@ def load_split(root, name, args, seed):
         it = ImageRecordIter(path_imgrec=rec, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True,
                              data_shape=(args.channels, args.image_size, args.image_size), batch_size=args.batch_size, seed=seed)
         lst = os.path.join(root, name + ".lst")
-        n = len(open(lst).readlines()) if os.path.exists(lst) else len(it.data_arr)
+        n = len(open(lst).readlines()) if os.path.exists(lst) else len(it)
         return it, n
     if args.synthetic:
         ids = max(args.synthetic // 4, 2)
