@@ -47,49 +47,116 @@ def parse():
     return ap.parse_args()
 
 
-def dominant_kernel_roofline(trainer, torch, iters=5):
-    """The heaviest single launch of the step is conv2 forward (66->198, 3x3, 56x56) with the fused bias+MFM+pool epilogue:
-    either the direct implicit-GEMM kernel conv_fwd_k<float,1,13,dma,fused> or, where autotune found it faster, the Winograd
-    F(2x2,3x3) kernel (wino4_k / wino_fwd_k).  Timed here with HIP events on the launch stream; algorithmic flops = unpadded
-    direct-convolution 2*M*N*K (the Winograd kernel executes 2.25x fewer multiplies for the same result)."""
+def kernel_families(trainer, torch, iters=3):
+    """The convolution launches of one training step, grouped by kernel instance (the names rocprofv3 reports): every distinct
+    (kernel, layer shape) is timed in isolation with HIP events on the launch stream; per instance: launches per step, ms per step,
+    ALGORITHMIC flops (unpadded direct-convolution 2*M*cout*cin*kh*kw — what `roofline.achieved` uses) and EXECUTED matrix-core
+    flops (padded tiles; a Winograd launch executes its 16 transformed-domain GEMMs = 1/2.25 of the algorithmic multiplies plus
+    padding), from efm_conv_kernel_info."""
     from improving_face_recognition_performance_using_triplet_loss_amd import ops
-    step = [s for s in trainer.plan.steps if s.op == "conv" and s.pname == "conv2"][0]
-    d = step.desc
-    v = trainer.plan.views(trainer.flat)
-    x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=trainer.device)
-    x[..., d.cin:] = 0
-    w, b = v["conv2_weight"], v["conv2_bias"]
-    epi = step.epi or {"ways": 3, "order": 0, "pool": True}
-    wino = bool(getattr(step, "wino_fwd", False)) and step.epi is not None
-    if wino:
-        u = ops.wino_mfm_make_u(d, w, epi["ways"])
-        run = lambda: ops.wino_mfm_fwd(d, x, u, b, epi["ways"], epi["order"], epi["pool"])  # noqa: E731
-        kernel = "%s (Winograd F(2x2,3x3), fused epilogue)" % ("wino4_k" if (d.tune_fwd >> 8) & 3 == 2 else "wino_fwd_k")
-    else:
-        run = lambda: ops.conv_mfm_fwd(d, x, w, b, epi["ways"], epi["order"], epi["pool"])  # noqa: E731
-        kernel = "conv_fwd_k<float,1,13,true,1>"
-    for _ in range(2):
+    plan, dev = trainer.plan, trainer.device
+    fam, cache = {}, {}
+
+    def timed(run):
         run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
-    achieved = flops / (ms * 1e-3) / 1e12
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def add(name, key, run, alg, exe):
+        if key not in cache:
+            cache[key] = timed(run)
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "alg_flop": 0.0, "mfma_flop": 0.0})
+        f["launches"] += 1
+        f["ms"] += cache[key]
+        f["alg_flop"] += alg
+        f["mfma_flop"] += exe
+
+    for st in plan.steps:
+        if st.op != "conv":
+            continue
+        d = st.desc
+        shape = (d.hin, d.win, d.cin, d.cout, d.kh, d.pad_h, st.epi is not None and (st.epi["ways"], st.epi["pool"]), d.tune_fwd, d.tune_dgrad,
+                 d.tune_wgrad, bool(getattr(st, "wino_fwd", False)), bool(getattr(st, "wino_dgrad", False)))
+        alg = 2.0 * d.batch * d.hout * d.wout * d.cout * d.cin * d.kh * d.kw
+        x = torch.rand((d.batch, d.hin, d.win, d.cin_p), device=dev)
+        x[..., d.cin:] = 0
+        dy = torch.rand((d.batch, d.hout, d.wout, d.cout_p), device=dev)
+        dy[..., d.cout:] = 0
+        w = torch.rand((d.n_pad16, d.k_pad), device=dev)
+        b = torch.zeros(d.n_pad16, device=dev)
+        e = st.epi
+        if e is not None:
+            if getattr(st, "wino_fwd", False):
+                u = ops.wino_mfm_make_u(d, w, e["ways"])
+                name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_FUSED, e["ways"], e["pool"])
+                add(name, ("f",) + shape, lambda: ops.wino_mfm_fwd(d, x, u, b, e["ways"], e["order"], e["pool"]), alg, exe)
+            else:
+                name, exe = ops.conv_kernel_info(d, ops.PASS_FUSED, e["ways"], e["pool"])
+                add(name, ("f",) + shape, lambda: ops.conv_mfm_fwd(d, x, w, b, e["ways"], e["order"], e["pool"]), alg, exe)
+        else:
+            y = torch.empty_like(dy)
+            if getattr(st, "wino_fwd", False):
+                u = ops.wino_make_u(d, w)
+                name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_FWD)
+                add(name, ("f",) + shape, lambda: ops.wino_fwd(d, x, u, b, out=y), alg, exe)
+            else:
+                name, exe = ops.conv_kernel_info(d, ops.PASS_FWD)
+                add(name, ("f",) + shape, lambda: ops.conv_fwd(d, x, w, b, out=y), alg, exe)
+        if st.inputs[0].needs_grad:
+            dx = torch.empty_like(x)
+            if getattr(st, "wino_dgrad", False):
+                u = ops.wino_make_u(d, w, dgrad=True)
+                name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_DGRAD)
+                add(name, ("d",) + shape, lambda: ops.wino_bwd_data(d, dy, u, out=dx), alg, exe)
+            else:
+                wd = torch.rand((d.dn_pad16, d.dk_pad), device=dev)
+                name, exe = ops.conv_kernel_info(d, ops.PASS_DGRAD)
+                add(name, ("d",) + shape, lambda: ops.conv_bwd_data(d, dy, wd, out=dx), alg, exe)
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        name, exe = ops.conv_kernel_info(d, ops.PASS_WGRAD)
+        add(name + " (+ wgrad_reduce_k)", ("w",) + shape, lambda: ops.conv_bwd_weight(d, x, dy, dw=dw, dbias=db), alg, exe)
+        del x, dy, w
+    return fam
+
+
+def dominant_kernel_roofline(trainer, torch, iters=3):
+    """`roofline` = the kernel instance that costs the most time per step (all its launches of a step together: sum of algorithmic
+    flops / sum of launch durations, each timed with HIP events on the launch stream, kernel alone on the chip), with the executed
+    matrix-core flops and the busy fraction they imply next to the algorithmic figure, and the per-instance table it was picked from."""
+    fam = kernel_families(trainer, torch, iters)
+    table = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        t = f["ms"] * 1e-3
+        table.append({"kernel": name, "launches_per_step": f["launches"], "ms_per_step": round(f["ms"], 3),
+                      "tflops_algorithmic": round(f["alg_flop"] / t / 1e12, 1), "tflops_mfma_executed": round(f["mfma_flop"] / t / 1e12, 1),
+                      "frac_algorithmic": round(f["alg_flop"] / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "mfma_busy_frac": round(f["mfma_flop"] / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
+    top_name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    t = top["ms"] * 1e-3
+    achieved = top["alg_flop"] / t / 1e12
     traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), same kernel only
-        prof = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic.json")))
-        if prof.get("kernel", "conv_fwd_k").split("<")[0].split(" ")[0] == kernel.split("<")[0].split(" ")[0]:
+    try:  # HBM bytes per launch of the SAME kernel instance from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        prof = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic.json")))
+        if prof.get("kernel", "").replace(" ", "") == top_name.replace(" ", ""):
             traffic = prof["traffic"]
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "%s: conv2 forward 66->198 3x3 @56x56 + bias + MFM3 + pool, B=%d" % (kernel, d.batch),
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "flop_per_launch": flops, "ms_per_launch": round(ms, 4), "winograd": wino, "tune_fwd": int(d.tune_fwd)}
+    conv_ms = sum(f["ms"] for f in fam.values())
+    return {"bound": "mfma", "kernel": "%s: the %d launches of one step (every layer that resolves to this instance), kernel alone on the chip"
+                                       % (top_name, top["launches"]),
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": traffic, "flop_per_launch": top["alg_flop"] / top["launches"], "ms_per_launch": round(top["ms"] / top["launches"], 4),
+            "launches_per_step": top["launches"], "ms_per_step": round(top["ms"], 3),
+            "mfma_flop_executed": top["mfma_flop"] / top["launches"],
+            "mfma_busy_frac": round(top["mfma_flop"] / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "note": "frac = ALGORITHMIC direct-convolution flops / time / peak; a Winograd F(2x2,3x3) kernel executes 2.25x fewer multiplies "
+                    "for them, so mfma_busy_frac (executed matrix-core flops / time / peak) is the utilisation of the matrix pipe",
+            "conv_kernel_ms_per_step_serial": round(conv_ms, 3), "families": table[:8]}
 
 
 def cpu_baseline(batch, image, torch):

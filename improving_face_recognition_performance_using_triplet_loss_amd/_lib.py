@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libefm_hip.so")
+LIB_PATH = os.environ.get("EFM_LIB_PATH") or os.path.join(HERE, "libefm_hip.so")  # EFM_LIB_PATH: A/B runs of two builds (tools/)
 
 EFM_OK = 0
 MFM_ORDER_GROUP = 0
@@ -94,6 +94,7 @@ SIGNATURES = {
     "efm_pred_get_output_shape": (c_int, [c_void_p, ctypes.c_uint32, POINTER(POINTER(ctypes.c_uint32)), POINTER(ctypes.c_uint32)]),
     "efm_pred_get_output": (c_int, [c_void_p, ctypes.c_uint32, c_void_p, ctypes.c_uint32]),
     "efm_pred_free": (c_int, [c_void_p]),
+    "efm_conv_kernel_info": (c_int, [POINTER(ConvDesc), c_int, c_int, c_int, ctypes.c_char_p, c_size_t, POINTER(ctypes.c_double)]),
     "efm_sgd_update": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),
     "efm_adam_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [c_float] * 6 + [c_int, c_void_p]),
 }

@@ -36,6 +36,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s);
 // bias_grad: dbias[n_pad16] (+)= column sums of dy (M x cout_p); ws holds bias_grad_ws_floats(d) floats.
 size_t bias_grad_ws_floats(const efm_conv_desc* d);
+// Kernel instance name + executed MFMA flops of a Winograd launch (defined in efm_winograd.hip; passes 4..6 of efm_conv_kernel_info).
+int wino_kernel_info(const efm_conv_desc* d, int pass, int ways, char* name, size_t len, double* flops);
 int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s);
 
 // Raw-buffer offsets are 32 bits and the kernels use byte offset 2^31 (EFM_OOB) as the "always out of range" address that the

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <string.h>
 
+#include <type_traits>
+
 #include "efm_common.h"
 
 namespace {
@@ -469,6 +471,8 @@ struct WgradP {
   int kblocks, nblocks, splits;
   int m_per_split;
   int mma_blocks;
+  int ktiles, ntiles;  // 16-wide tiles of the packed gradient: k_pad / 16, n_pad16 / 16
+  int bias_rows;       // dy rows per column-sum block
   unsigned x_bytes, y_bytes;
 };
 
@@ -504,7 +508,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   const int split = bid / tiles;
   bid -= split * tiles;
   const int kb = bid / p.nblocks, nb = bid - kb * p.nblocks;
-  const int k0 = kb * BKR, n0 = nb * BNW;
+  // The 16-wide tiles of the gradient are dealt EVENLY to the k / n blocks (a block owns nkt <= 4*KPW k-tiles and nnt <= NTW
+  // n-tiles) and, inside a block, k-tile j goes to wave j % 4: tile slots a block does not own cost no MFMA — the matrix pipe of
+  // a SIMD is shared with the waves of the other resident blocks, so every skipped MFMA is theirs to use (with 8 or 13 slots per
+  // block and e.g. 25 k-tiles, padding the last block with zero tiles cost up to 28 % of a layer's MFMAs).
+  const int kt_begin = (int)(((long)kb * p.ktiles) / p.kblocks), nkt = (int)(((long)(kb + 1) * p.ktiles) / p.kblocks) - kt_begin;
+  const int nt_begin = (int)(((long)nb * p.ntiles) / p.nblocks), nnt = (int)(((long)(nb + 1) * p.ntiles) / p.nblocks) - nt_begin;
+  const int k0 = kt_begin * 16, n0 = nt_begin * 16;
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int hw = p.hout * p.wout;
@@ -522,7 +532,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   const int kglob = k0 + xk4 * 4;
   const int tap = kglob / p.cin_p, xc = kglob - tap * p.cin_p;
   const int xkh = tap / p.kw, xkw = tap - xkh * p.kw;
-  const bool xtap_ok = tap < p.kh * p.kw;
+  const bool xtap_ok = tap < p.kh * p.kw && xk4 * 4 < nkt * 16;
   const int xdoff = ((xkh - p.pad_h) * p.win + (xkw - p.pad_w)) * p.cin_p + xc;
 
   auto load_tile = [&](int step, int buf) {
@@ -548,7 +558,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
         int n4 = e - pp * N4;
         if (SWZ_Y) n4 ^= 4 * (pp & 1);
         const int m = mbase + pp, n = n0 + n4 * 4;
-        const bool v = m < m_end && n < p.cout_p;
+        const bool v = m < m_end && n < p.cout_p && n4 * 4 < nnt * 16;
         const unsigned off = v ? (unsigned)((m * p.cout_p + n) * 4) : EFM_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(Ys + (256 * j + 64 * wave) * 4),
                                                  16, off, 0, 0, 0);
@@ -564,19 +574,24 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
 
   const int fi = lane & 15, fq = lane >> 4;
   const int fx = 16 * (fq & 1);  // the read-side half of the XOR swizzle (16 floats = 4 pieces)
-  auto compute = [&](int buf) {
+  // k-tiles this wave owns: slots kt = 0 .. nkw-1 (slot kt holds the block's tile kt*4 + wave).  The MFMA loop exists once per
+  // possible count, fully unrolled and branch-free inside (a per-tile branch costs more than the MFMA it saves); the count is
+  // wave-uniform, so picking the loop is one scalar branch per 16-pixel step.
+  const int nkw = (nkt > wave) ? (nkt - wave + 3) / 4 : 0;
+  auto compute = [&](auto nk_tag, int buf) {
+    constexpr int NK = decltype(nk_tag)::value;
     const float* Xs = smem + buf * TILE;
     const float* Ys = Xs + BP * BKR;
 #pragma unroll
     for (int s = 0; s < BP / 4; ++s) {
-      float bx[KPW];
+      float bx[NK];
 #pragma unroll
-      for (int kt = 0; kt < KPW; ++kt) bx[kt] = Xs[(4 * s + fq) * BKR + (((wave * KPW + kt) * 16 + fi) ^ fx)];
+      for (int kt = 0; kt < NK; ++kt) bx[kt] = Xs[(4 * s + fq) * BKR + (((kt * 4 + wave) * 16 + fi) ^ fx)];
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const float ay = Ys[(4 * s + fq) * BNW + (SWZ_Y ? ((nt * 16 + fi) ^ fx) : (nt * 16 + fi))];
 #pragma unroll
-        for (int kt = 0; kt < KPW; ++kt)
+        for (int kt = 0; kt < NK; ++kt)
           acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bx[kt], acc[kt][nt], 0, 0, 0);
       }
     }
@@ -587,21 +602,23 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   __syncthreads();
   for (int t = 0; t < steps; ++t) {
     if (t + 1 < steps) load_tile(t + 1, (t + 1) & 1);
-    compute(t & 1);
+    if (nkw == KPW)
+      compute(std::integral_constant<int, KPW>{}, t & 1);
+    else if (KPW == 2 && nkw == 1)
+      compute(std::integral_constant<int, 1>{}, t & 1);
     __syncthreads();  // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
   }
 
   float* ws = p.ws + (long)split * p.n_pad16 * p.k_pad;
 #pragma unroll
   for (int kt = 0; kt < KPW; ++kt) {
-    const int k = k0 + (wave * KPW + kt) * 16 + fi;
-    if (k < p.k_pad) {
+    const int k = k0 + (kt * 4 + wave) * 16 + fi;
+    if (kt < nkw) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
+        if (nt < nnt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = n0 + nt * 16 + fq * 4 + r;
-          if (n < p.n_pad16) ws[(long)n * p.k_pad + k] = acc[kt][nt][r];
+          for (int r = 0; r < 4; ++r) ws[(long)(n0 + nt * 16 + fq * 4 + r) * p.k_pad + k] = acc[kt][nt][r];
         }
       }
     }
@@ -678,6 +695,47 @@ __global__ void __launch_bounds__(256) slab_reduce_k(const float* __restrict__ w
     if (accumulate) t += *o;
     *o = t;
   }
+}
+
+// The direct weight gradient's reduction as ONE launch: blocks [0, gx_w) sum the `splits` slabs of the packed gradient (64 float4
+// columns x 4 slab lanes per block), blocks [gx_w, ...) sum the `chunks` column-sum partials of the bias gradient (16 columns x 16
+// lanes: few columns, up to 3136 partials).  Every output element is a fixed-order sum (lane l takes slabs l, l+L, ..., then the
+// lanes are added in index order): bitwise reproducible, no atomics.
+template <int COLS, int LANES>
+__device__ __forceinline__ void reduce_part(const float* __restrict__ in, float* __restrict__ out, long n4, int count, int accumulate,
+                                            int bx, float* red) {
+  const int cx = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const long i = (long)bx * COLS + cx;
+  const f32x4* w = reinterpret_cast<const f32x4*>(in);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (i < n4) {
+    int k = sl;
+    for (; k + LANES < count; k += 2 * LANES) {  // two independent chains keep more loads in flight
+      s0 += w[(long)k * n4 + i];
+      s1 += w[(long)(k + LANES) * n4 + i];
+    }
+    if (k < count) s0 += w[(long)k * n4 + i];
+  }
+  *reinterpret_cast<f32x4*>(red + (sl * COLS + cx) * 4) = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    f32x4 t = *reinterpret_cast<f32x4*>(red + cx * 4);
+#pragma unroll
+    for (int l = 1; l < LANES; ++l) t += *reinterpret_cast<f32x4*>(red + (l * COLS + cx) * 4);
+    f32x4* o = reinterpret_cast<f32x4*>(out) + i;
+    if (accumulate) t += *o;
+    *o = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_k(const float* __restrict__ slabs, float* __restrict__ dw, long n4w, int splits,
+                                                      const float* __restrict__ bpart, float* __restrict__ dbias, long n4b, int chunks,
+                                                      int accumulate, int gx_w) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
+  if ((int)blockIdx.x < gx_w)
+    reduce_part<64, 4>(slabs, dw, n4w, splits, accumulate, (int)blockIdx.x, red);
+  else
+    reduce_part<16, 16>(bpart, dbias, n4b, chunks, accumulate, (int)blockIdx.x - gx_w, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -791,6 +849,31 @@ int pick_mt_bf16(long M, int nblocks) {
   return 1;
 }
 
+struct FwdTiling {
+  int NT, MT, nblocks;
+};
+
+// Block shape of the plain forward / data-gradient launch: NT 16-column tiles x 64*MT rows (shared by run_fwd and efm_conv_kernel_info).
+FwdTiling fwd_tiling(long M, int n_pad16, int tune, int esize) {
+  FwdTiling ft;
+  const int tiles = n_pad16 / 16;
+  int nblocks = (tiles + 12) / 13;
+  if (((tune >> 4) & 15) > nblocks) nblocks = std::min((tune >> 4) & 15, tiles);  // bits 9:8 belong to the Winograd kernels
+  const int NT = round_nt((tiles + nblocks - 1) / nblocks);
+  ft.nblocks = (tiles + NT - 1) / NT;
+  // 64-row tiles (52 accumulator registers at NT = 13 -> 4 blocks per CU) measured equal or better than 128-row
+  // tiles for NT >= 7; narrow tiles (NT <= 6) amortise the pixel-tile staging better with 128 rows.
+  int MT = (NT >= 7) ? 1 : 2;
+  if ((long)efm::cdiv(M, 128) * ft.nblocks < 1024) MT = 1;
+  if (esize == 2) MT = pick_mt_bf16(M, ft.nblocks);
+  if ((tune & 15) == 1 || (tune & 15) == 2 || ((tune & 15) == 4 && esize == 2)) MT = tune & 15;
+  MT = env_int("EFM_CONV_MT", MT);
+  if (esize == 4 && MT > 2) MT = 2;
+  ft.MT = mt_fit(MT, NT);
+  ft.NT = NT;
+  return ft;
+}
+
 // Generic forward-type launch: y[m][n] = sum_k A(x)[m][k] w[n][k] + bias[n] + res[m][n]
 template <typename T>
 int run_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, int batch,
@@ -805,20 +888,9 @@ int run_fwd(const void* x, const void* w, const float* bias, const void* res, vo
   p.kh = kh; p.kw = kw; p.pad_h = pad_h; p.pad_w = pad_w;
   p.n_pad16 = n_pad16; p.k_pad = k_pad; p.ksteps = k_pad / KS;
   p.route = nullptr; p.cout = 0; p.ways = 0; p.order = 0; p.pool = 0; p.hp = 0; p.wp = 0; p.cn = 0; p.cpo = 0; p.out_f32 = 1;
-  const int tiles = n_pad16 / 16;
-  int nblocks = (tiles + 12) / 13;
-  if (((tune >> 4) & 15) > nblocks) nblocks = std::min((tune >> 4) & 15, tiles);  // bits 9:8 belong to the Winograd kernels
-  const int NT = round_nt((tiles + nblocks - 1) / nblocks);
-  p.nblocks = (tiles + NT - 1) / NT;
-  // 64-row tiles (52 accumulator registers at NT = 13 -> 4 blocks per CU) measured equal or better than 128-row
-  // tiles for NT >= 7; narrow tiles (NT <= 6) amortise the pixel-tile staging better with 128 rows.
-  int MT = (NT >= 7) ? 1 : 2;
-  if ((long)efm::cdiv(p.M, 128) * p.nblocks < 1024) MT = 1;
-  if (sizeof(T) == 2) MT = pick_mt_bf16(p.M, p.nblocks);
-  if ((tune & 15) == 1 || (tune & 15) == 2 || ((tune & 15) == 4 && sizeof(T) == 2)) MT = tune & 15;
-  MT = env_int("EFM_CONV_MT", MT);
-  if (sizeof(T) == 4 && MT > 2) MT = 2;
-  MT = mt_fit(MT, NT);
+  const FwdTiling ft = fwd_tiling(p.M, n_pad16, tune, (int)sizeof(T));
+  const int NT = ft.NT, MT = ft.MT;
+  p.nblocks = ft.nblocks;
   const int BM = 64 * MT;
   const long mblocks = efm::cdiv(p.M, BM);
   dim3 grid((unsigned)(mblocks * p.nblocks));
@@ -881,14 +953,14 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   mps = (mps + 15) & ~15;
   pl.m_per_split = mps;
   pl.splits = (M + mps - 1) / mps;
-  // slabs are summed 32 at a time per thread at most: more than that goes through a second level
-  pl.per_group = (pl.splits > 32) ? 32 : pl.splits;
-  pl.groups = (pl.splits + pl.per_group - 1) / pl.per_group;
+  // slabs and bias partials are reduced by ONE launch (wgrad_reduce_k), single level
+  pl.per_group = pl.splits;
+  pl.groups = 1;
   pl.slab_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad;
-  pl.lvl2_floats = (pl.groups > 1) ? (size_t)pl.groups * d->n_pad16 * d->k_pad : 0;
+  pl.lvl2_floats = 0;
   pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
-  pl.bias_groups = (pl.bias_chunks + 31) / 32;
-  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + (size_t)(pl.bias_chunks + pl.bias_groups) * d->n_pad16;
+  pl.bias_groups = 0;
+  pl.ws_floats = pl.slab_floats + (size_t)pl.bias_chunks * d->n_pad16;
   return pl;
 }
 
@@ -1282,17 +1354,18 @@ int efm_conv_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, 
                  d->kh, d->kw, d->pad_h, d->pad_w, d->n_pad16, d->k_pad, d->tune_fwd, (hipStream_t)stream);
 }
 
-int efm_conv_mfm_supported(const efm_conv_desc* d) { return d != nullptr; }
+}  // extern "C"
 
-int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
-                     unsigned char* route, int ways, int order, int pool, void* stream) {
-  EFM_REQUIRE(d && x && w_packed && z && route, "conv_mfm_fwd: null argument");
-  EFM_REQUIRE_RANGE(d, 4, "conv_mfm_fwd");
-  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
-  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
-  EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
-  // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default (measured on EFM-29): one block up
-  // to 13 column tiles, two above (387- and 261-channel layers: 13- / 9-tile blocks beat one 25- / 17-tile block).
+namespace {
+struct EpiTiling {
+  int nsplit, cn, NT, MT;
+};
+
+// Channel blocks of the fused conv -> MFM (-> pool) forward: each owns cn channels of every slice (ways * cn columns).  Default
+// (measured on EFM-29): one block up to 13 column tiles, two above (387- and 261-channel layers: 13- / 9-tile blocks beat one
+// 25- / 17-tile block).  Shared by efm_conv_mfm_fwd and efm_conv_kernel_info.
+EpiTiling epi_tiling(const efm_conv_desc* d, int ways) {
+  EpiTiling et;
   const int cs_all = d->cout / ways;
   int nsplit = env_int("EFM_EPI_NSPLIT", (d->tune_fwd >> 4) & 15);
   if (nsplit <= 0) nsplit = (ways * cs_all > 13 * 16) ? 2 : 1;
@@ -1306,6 +1379,30 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
     nsplit = (cs_all + cn - 1) / cn;
     NT = round_nt_epi((ways * cn + 15) / 16);
   }
+  et.nsplit = nsplit; et.cn = cn; et.NT = NT;
+  // 128-row tiles (tune_fwd & 15 == 2) halve the weight-tile traffic per pixel: pays for the short-K layers (conv1, the 1x1s)
+  et.MT = NT > 0 ? mt_fit(((d->tune_fwd & 15) == 2) ? env_int("EFM_EPI_MT", 2) : env_int("EFM_EPI_MT", 1), NT) : 1;
+  return et;
+}
+
+}  // namespace
+
+extern "C" {
+
+int efm_conv_mfm_supported(const efm_conv_desc* d) { return d != nullptr; }
+
+int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_packed, const float* bias, float* z,
+                     unsigned char* route, int ways, int order, int pool, void* stream) {
+  EFM_REQUIRE(d && x && w_packed && z && route, "conv_mfm_fwd: null argument");
+  EFM_REQUIRE_RANGE(d, 4, "conv_mfm_fwd");
+  EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_mfm_fwd: cout=%d not divisible by ways=%d", d->cout, ways);
+  EFM_REQUIRE(order == EFM_MFM_ORDER_GROUP || order == EFM_MFM_ORDER_RES, "conv_mfm_fwd: bad order %d", order);
+  EFM_REQUIRE(!pool || (d->hout >= 2 && d->wout >= 2), "conv_mfm_fwd: pooling needs a map of at least 2x2");
+  // channel blocks: each owns cn channels of every slice (ways * cn columns).  Default (measured on EFM-29): one block up
+  // to 13 column tiles, two above (387- and 261-channel layers: 13- / 9-tile blocks beat one 25- / 17-tile block).
+  const int cs_all = d->cout / ways;
+  const EpiTiling et = epi_tiling(d, ways);
+  const int nsplit = et.nsplit, cn = et.cn, NT = et.NT;
   EFM_REQUIRE(NT > 0, "conv_mfm_fwd: no tiling for %d output channels", d->cout);
   ConvP p;
   p.x = x; p.w = w_packed; p.bias = bias; p.res = nullptr; p.y = z;
@@ -1325,7 +1422,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.w_bytes = (unsigned)((size_t)d->n_pad16 * d->k_pad * sizeof(float));
   // 128-row tiles (tune_fwd & 15 == 2) halve the weight-tile traffic per pixel: pays for the short-K layers (conv1, the 1x1s)
-  const int MT = mt_fit(((d->tune_fwd & 15) == 2) ? env_int("EFM_EPI_MT", 2) : env_int("EFM_EPI_MT", 1), NT);
+  const int MT = et.MT;
   dim3 grid((unsigned)(efm::cdiv(p.M, 64 * MT) * nsplit));
   int rc = (MT == 2) ? launch_fwd_epi<float, 2>(NT, grid, (hipStream_t)stream, p) : launch_fwd_epi<float, 1>(NT, grid, (hipStream_t)stream, p);
   if (rc != EFM_OK) return rc;
@@ -1376,29 +1473,57 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   float* slabs = (float*)workspace;
   float* lvl2 = slabs + pl.slab_floats;
   float* bpart = lvl2 + pl.lvl2_floats;
-  float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
   p.bias_part = dbias ? bpart : nullptr;
+  p.ktiles = d->k_pad / 16; p.ntiles = d->n_pad16 / 16; p.bias_rows = BIAS_ROWS;
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
   dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
   if (rc != EFM_OK) return rc;
   rc = efm::check_launch("conv_wgrad");
   if (rc != EFM_OK) return rc;
-  auto reduce = [&](const float* in, float* tmp, float* out, long n4, int count) -> int {
-    const unsigned gx = (unsigned)efm::cdiv(n4, 64);
-    if (count > 32) {
-      const int groups = (count + 31) / 32;
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, in, tmp, n4, n4, count, 32, n4, 0);
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, groups, groups, n4, accumulate);
-    } else {
-      hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, count, count, n4, accumulate);
-    }
-    return efm::check_launch("conv_wgrad_reduce");
-  };
-  rc = reduce(slabs, lvl2, dw_packed, (long)d->n_pad16 * d->k_pad / 4, pl.splits);
-  if (rc != EFM_OK) return rc;
-  if (dbias) rc = reduce(bpart, bpart2, dbias, d->n_pad16 / 4, pl.bias_chunks);
-  return rc;
+  const long n4w = (long)d->n_pad16 * d->k_pad / 4, n4b = d->n_pad16 / 4;
+  const int gx_w = (int)efm::cdiv(n4w, 64), gx_b = dbias ? (int)efm::cdiv(n4b, 16) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, s, (const float*)slabs, dw_packed, n4w, pl.splits,
+                     (const float*)bpart, dbias, n4b, pl.bias_chunks, accumulate, gx_w);
+  return efm::check_launch("conv_wgrad_reduce");
+}
+
+
+/* Diagnostic for roofline accounting (bench.py): which kernel instance a launch of `pass` resolves to under the descriptor's tuning
+ * fields, and the matrix-core flops it EXECUTES (padded tiles; Winograd: the 16 transformed-domain GEMMs) — as opposed to the
+ * algorithmic 2*M*cout*cin*kh*kw.  pass: 0 forward, 1 forward + fused MFM(ways) epilogue (`pool`), 2 data gradient, 3 weight
+ * gradient, 4 / 5 / 6 = Winograd forward / fused forward / data gradient. */
+int efm_conv_kernel_info(const efm_conv_desc* d, int pass, int ways, int pool, char* name, size_t name_len, double* mfma_flops) {
+  EFM_REQUIRE(d && pass >= 0 && pass <= 6, "conv_kernel_info: bad argument");
+  if (pass >= 4) {
+    EFM_REQUIRE(efm::wino_kernel_info(d, pass, ways, name, name_len, mfma_flops) == EFM_OK, "conv_kernel_info: not a Winograd geometry");
+    return EFM_OK;
+  }
+  const long M = (long)d->batch * d->hout * d->wout;
+  double fl = 0.0;
+  char buf[96];
+  if (pass == 0 || pass == 2) {
+    const long rows = pass == 0 ? M : (long)d->batch * d->hin * d->win;
+    const FwdTiling ft = pass == 0 ? fwd_tiling(rows, d->n_pad16, d->tune_fwd, 4) : fwd_tiling(rows, d->dn_pad16, d->tune_dgrad, 4);
+    const long bm = 64 * ft.MT;
+    fl = 2.0 * (double)(efm::cdiv(rows, bm) * bm) * (double)(ft.nblocks * ft.NT * 16) * (double)(pass == 0 ? d->k_pad : d->dk_pad);
+    snprintf(buf, sizeof(buf), "conv_fwd_k<float, %d, %d, true, 0>", ft.MT, ft.NT);
+  } else if (pass == 1) {
+    EFM_REQUIRE((ways == 2 || ways == 3) && d->cout % ways == 0, "conv_kernel_info: cout=%d not divisible by ways=%d", d->cout, ways);
+    const EpiTiling et = epi_tiling(d, ways);
+    EFM_REQUIRE(et.NT > 0, "conv_kernel_info: no fused tiling");
+    const long rows = pool ? (long)d->batch * (d->hout / 2) * (d->wout / 2) * 4 : M;
+    const long bm = 64 * et.MT;
+    fl = 2.0 * (double)(efm::cdiv(rows, bm) * bm) * (double)(et.nsplit * et.NT * 16) * (double)d->k_pad;
+    snprintf(buf, sizeof(buf), "conv_fwd_k<float, %d, %d, true, 1>", et.MT, et.NT);
+  } else {
+    const WgradPlan pl = plan_wgrad(d);
+    fl = 2.0 * (double)((long)pl.splits * pl.m_per_split) * (double)(pl.nblocks * pl.NTW * 16) * (double)d->k_pad;
+    snprintf(buf, sizeof(buf), "conv_wgrad_k<%d, %d>", pl.KPW, pl.NTW);
+  }
+  if (name && name_len) snprintf(name, name_len, "%s", buf);
+  if (mfma_flops) *mfma_flops = fl;
+  return EFM_OK;
 }
 
 
@@ -1528,6 +1653,7 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
   float* bpart = lvl2 + pl.lvl2_floats;
   float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
   p.bias_part = dbias ? bpart : nullptr;
+
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
   dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
   int rc = (pl.KPW == 2) ? launch_wgradb_nt<2>(pl.NTW, grid, s, p) : launch_wgradb_nt<1>(pl.NTW, grid, s, p);

@@ -38,6 +38,11 @@ struct WinoP {
   float* y;
   int batch, h, w, cin_p, cout_p;
   int th, tw, tiles;  // tile grid per image, total tiles
+  // ceil(2^32 / (th*tw)), ceil(2^32 / tw): tile -> (image, row, column) by one v_mul_hi_u32 against an SGPR each.  A plain `/` made
+  // the compiler keep two per-lane reciprocals alive from the prologue to the epilogue — the two VGPRs wino4_k<3> (192 accumulators)
+  // spilled.  Exact while tiles * th*tw < 2^32 (checked on the host).
+  unsigned magic_per, magic_tw;  // 0 when the divisor is 1 (2^32 does not fit): one_per / one_tw = 1 then adds n back
+  int one_per, one_tw;
   int kpad, chunks, nblocks;
   unsigned x_bytes, u_bytes;
   int dbg;
@@ -62,8 +67,8 @@ __device__ __forceinline__ void wino_final(const WinoP& p, const float* Rs, floa
       const int a = rest & 1, tl = rest >> 1;
       const int tile = t0 + tl, n = n0 + cq * 4;
       if (tile >= p.tiles || n >= p.cout_p) continue;
-      const int b = tile / per, r = tile - b * per;
-      const int ty = r / p.tw, tx = r - ty * p.tw;
+      const int b = (int)__umulhi((unsigned)tile, p.magic_per) + tile * p.one_per, r = tile - b * per;
+      const int ty = (int)__umulhi((unsigned)r, p.magic_tw) + r * p.one_tw, tx = r - ty * p.tw;
       const int oy = 2 * ty + a, ox = 2 * tx + bb;
       if (oy >= p.h || ox >= p.w) continue;
       const f32x4 r1 = *reinterpret_cast<const f32x4*>(Rs + (1 * TB + tl) * RS + cq * 4);
@@ -87,8 +92,8 @@ __device__ __forceinline__ void wino_final(const WinoP& p, const float* Rs, floa
     const int j = it % cnb, tl = it / cnb;
     const int tile = t0 + tl;
     if (tile >= p.tiles) continue;
-    const int b = tile / per, r = tile - b * per;
-    const int ty = r / p.tw, tx = r - ty * p.tw;
+    const int b = (int)__umulhi((unsigned)tile, p.magic_per) + tile * p.one_per, r = tile - b * per;
+    const int ty = (int)__umulhi((unsigned)r, p.magic_tw) + r * p.one_tw, tx = r - ty * p.tw;
     float ya[2][3];
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
@@ -168,8 +173,8 @@ __device__ __forceinline__ void wino_final(const WinoP& p, const float* Rs, floa
       const int a = rest & 1, tl = rest >> 1;
       const int tile = t0 + tl;
       if (tile >= p.tiles) continue;
-      const int b = tile / per, r = tile - b * per;
-      const int ty = r / p.tw, tx = r - ty * p.tw;
+      const int b = (int)__umulhi((unsigned)tile, p.magic_per) + tile * p.one_per, r = tile - b * per;
+      const int ty = (int)__umulhi((unsigned)r, p.magic_tw) + r * p.one_tw, tx = r - ty * p.tw;
       if (p.pool) {
         if (bb == 1 && a == 0 && ty < hp && tx < wp) p.y[((long)(b * hp + ty) * wp + tx) * cpo + co + pc] = 0.f;
       } else {
@@ -215,8 +220,8 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
   unsigned xoff[4];
   {
     const int tile = t0 + tt;
-    const int b = tile / per, r = tile - b * per;
-    const int ty = r / p.tw, tx = r - ty * p.tw;
+    const int b = (int)__umulhi((unsigned)tile, p.magic_per) + tile * p.one_per, r = tile - b * per;
+    const int ty = (int)__umulhi((unsigned)r, p.magic_tw) + r * p.one_tw, tx = r - ty * p.tw;
     const int ix = 2 * tx - 1 + c;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -371,8 +376,8 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
   unsigned xoff[4];
   {
     const int tile = t0 + tt;
-    const int b = tile / per, r = tile - b * per;
-    const int ty = r / p.tw, tx = r - ty * p.tw;
+    const int b = (int)__umulhi((unsigned)tile, p.magic_per) + tile * p.one_per, r = tile - b * per;
+    const int ty = (int)__umulhi((unsigned)r, p.magic_tw) + r * p.one_tw, tx = r - ty * p.tw;
     const int ix = 2 * tx - 1 + c;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -824,6 +829,10 @@ int run_wino(const float* x, const float* u, const float* bias, const float* res
   p.x = x; p.u = u; p.bias = bias; p.res = res; p.y = y;
   p.batch = batch; p.h = h; p.w = w; p.cin_p = cin_p; p.cout_p = cout_p;
   p.th = (h + 1) / 2; p.tw = (w + 1) / 2; p.tiles = batch * p.th * p.tw;
+  EFM_REQUIRE((unsigned long long)p.tiles * (unsigned)(p.th * p.tw) < 0x100000000ULL, "winograd: batch * tiles-per-image^2 must stay below 2^32");
+  p.one_per = (p.th * p.tw == 1); p.one_tw = (p.tw == 1);
+  p.magic_per = p.one_per ? 0u : (unsigned)((0x100000000ULL + (unsigned)(p.th * p.tw) - 1) / (unsigned)(p.th * p.tw));
+  p.magic_tw = p.one_tw ? 0u : (unsigned)((0x100000000ULL + (unsigned)p.tw - 1) / (unsigned)p.tw);
   p.kpad = pl.kpad; p.chunks = pl.kpad / (pl.variant == 4 ? KC4 : KC); p.nblocks = pl.nblocks;
   p.x_bytes = (unsigned)((size_t)batch * h * w * cin_p * 4);
   p.u_bytes = (unsigned)((size_t)16 * pl.n_rows * pl.kpad * 4);
@@ -849,6 +858,25 @@ int run_wino(const float* x, const float* u, const float* bias, const float* res
 }
 
 }  // namespace
+
+extern "C" {
+
+}  // extern "C"
+
+namespace efm {
+// Kernel instance and EXECUTED matrix-core flops of a Winograd launch (16 GEMMs of [tiles padded to 64] x [n_rows] x [kpad]).
+// pass: 4 = forward, 5 = forward with fused epilogue (`ways`), 6 = data gradient.
+int wino_kernel_info(const efm_conv_desc* d, int pass, int ways, char* name, size_t len, double* flops) {
+  if (!efm_wino_supported(d)) return EFM_E_INVALID;
+  const bool dg = pass == 6;
+  const WinoPlan pl = dg ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd, pass == 5 ? ways : 0);
+  const long tiles = (long)d->batch * ((d->hin + 1) / 2) * ((d->win + 1) / 2);
+  const long tiles_pad = (tiles + TB - 1) / TB * TB;
+  if (name) snprintf(name, len, "%s<%d>", pl.variant == 4 ? "wino4_k" : "wino_fwd_k", pl.NTB);
+  if (flops) *flops = 2.0 * 16.0 * (double)tiles_pad * (double)pl.n_rows * (double)pl.kpad;
+  return EFM_OK;
+}
+}  // namespace efm
 
 extern "C" {
 

@@ -439,6 +439,18 @@ def convb_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=F
 
 
 # ---- Winograd F(2x2, 3x3) form of the 3x3 / pad 1 convolutions ----------------------------------------------------------
+PASS_FWD, PASS_FUSED, PASS_DGRAD, PASS_WGRAD, PASS_WINO_FWD, PASS_WINO_FUSED, PASS_WINO_DGRAD = range(7)
+
+
+def conv_kernel_info(d, pass_, ways=0, pool=False):
+    """-> (kernel instance name, matrix-core flops the launch EXECUTES) for roofline accounting (efm_conv_kernel_info)."""
+    name = ctypes.create_string_buffer(96)
+    fl = ctypes.c_double()
+    check(_lib.load().efm_conv_kernel_info(ctypes.byref(d), int(pass_), int(ways), int(bool(pool)), name, 96, ctypes.byref(fl)),
+          "efm_conv_kernel_info")
+    return name.value.decode(), fl.value
+
+
 def wino_supported(d):
     return bool(_lib.load().efm_wino_supported(ctypes.byref(d)))
 

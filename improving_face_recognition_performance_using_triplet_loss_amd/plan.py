@@ -582,7 +582,7 @@ class Plan:
             # weight gradient: 64 / 128 weight columns per block x the number of pixel splits (summation order differs, nothing else)
             dwt = torch.empty((d.n_pad16, d.k_pad), device=self.device)
             dbt = torch.empty((d.n_pad16,), device=self.device)
-            cw = [0] + [kpw | ((blocks // 64) << 4) for kpw in (1, 2) for blocks in (1536, 2560, 3840)]
+            cw = [0] + [kpw | ((blocks // 64) << 4) for kpw in (1, 2) for blocks in (768, 1024, 1536, 2560, 3840)]
             chosen[st.pname + ":wgrad"] = best(lambda: ops.conv_bwd_weight(d, x, dy, dw=dwt, dbias=dbt), d, "tune_wgrad", cw)[0]
             seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad, d.tune_wgrad)
         if verbose:

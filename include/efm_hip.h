@@ -257,6 +257,14 @@ int efm_mine_semihard(const float* g, const int32_t* labels, const int32_t* anch
                       const int32_t* pos_idx, int32_t* neg_idx, int n_anchor, int rows, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Diagnostic (no reference call site: bench.py's roofline accounting).  Which kernel instance a convolution launch resolves
+ * to under the descriptor's tuning fields, and the matrix-core flops that launch EXECUTES (padded tiles; Winograd: the 16
+ * transformed-domain GEMMs), as opposed to the algorithmic 2*M*cout*cin*kh*kw.  pass: 0 forward, 1 forward + fused MFM(ways)
+ * (+ pool) epilogue, 2 data gradient, 3 weight gradient, 4 / 5 / 6 = Winograd forward / fused forward / data gradient.
+ * ------------------------------------------------------------------------------------ */
+int efm_conv_kernel_info(const efm_conv_desc* d, int pass, int ways, int pool, char* name, size_t name_len, double* mfma_flops);
+
+/* ------------------------------------------------------------------------------------
  * Optimiser on the flat packed parameter buffer.
  * SGD: w -= lr*(rescale*g + wd*w)                    (ref: pre-trained_efm_v3.py:185,212)
  * Adam (MXNet form): g' = rescale*g + wd*w; m,v EMA; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)

@@ -79,6 +79,8 @@ def test_every_selected_kernel_matches_its_direct_counterpart_at_the_real_shape(
             else:
                 z, r = ops.conv_mfm_fwd(d, x, w, bias, e["ways"], e["order"], e["pool"])
             errs["fused"] = float((z - zr).abs().max() / zr.abs().max())
+            creal = ops.mfm_out_channels(d.cout, e["ways"])      # route bytes of the pad channels are never written: unspecified
+            r, rr = r[..., :creal], rr[..., :creal]
             flips = float((r != rr).float().mean())
             errs["route_flips"] = flips
             assert flips < 1e-4, (st.pname, flips)      # a route differs only where two candidates agree to the last bits
