@@ -43,11 +43,12 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 (lightcnn9 only) = BASELINE configs[2]: bf16 operands / activations, fp32 accumulate + master weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bounded bf16 runs of BASELINE configs[2] / configs[4]")
     ap.add_argument("--cpu-batch", type=int, default=64, help="images of the CPU-baseline sample: BASELINE configs[0] = 64 faces (~30 s of host work)")
     return ap.parse_args()
 
 
-def kernel_families(trainer, torch, iters=3):
+def kernel_families(trainer, torch, iters=3, only=None, dedup=True):
     """The convolution launches of one training step, grouped by kernel instance (the names rocprofv3 reports): every distinct
     (kernel, layer shape) is timed in isolation with HIP events on the launch stream; per instance: launches per step, ms per step,
     ALGORITHMIC flops (unpadded direct-convolution 2*M*cout*cin*kh*kw — what `roofline.achieved` uses) and EXECUTED matrix-core
@@ -68,7 +69,9 @@ def kernel_families(trainer, torch, iters=3):
         return e0.elapsed_time(e1) / iters
 
     def add(name, key, run, alg, exe):
-        if key not in cache:
+        if only is not None and not name.startswith(only):  # tools/family_probe.py: just this kernel instance (rocprofv3 --pmc passes)
+            return
+        if key not in cache or not dedup:  # dedup=False (profiling probe): launch mix = the step's, repeated shapes included
             cache[key] = timed(run)
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "alg_flop": 0.0, "mfma_flop": 0.0})
         f["launches"] += 1
@@ -157,6 +160,36 @@ def dominant_kernel_roofline(trainer, torch, iters=3):
             "note": "frac = ALGORITHMIC direct-convolution flops / time / peak; a Winograd F(2x2,3x3) kernel executes 2.25x fewer multiplies "
                     "for them, so mfma_busy_frac (executed matrix-core flops / time / peak) is the utilisation of the matrix pipe",
             "conv_kernel_ms_per_step_serial": round(conv_ms, 3), "families": table[:8]}
+
+
+def secondary_configs(torch, device, image, steps=10, warmup=3):
+    """BASELINE configs[2] and configs[4] (one GPU each), a few seconds in all, inside the same JSON line so that a driver-timed
+    figure exists for them: LightCNN-9 256-d, 512 images, bf16, in-batch semi-hard mining (every image an anchor);
+    the build-defined deeper CNN 512-d, 128 images, bf16, same step.  Not the headline metric."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol, synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
+    res = {}
+    for key, batch, outputs, flop in (("configs[2] LightCNN-9 256-d B=512 bf16 semi-hard", 512, efm_symbol.lightcnn9_embedding_net, 4667572224),
+                                      ("configs[4] deeper CNN 512-d B=128 bf16 semi-hard", 128, efm_symbol.deepcnn_embedding_net, 3 * 5199839232 - 180633600)):
+        tr = MiningTripletTrainer(batch, image=image, optimizer="sgd", lr=2.4e-4, wd=1e-5, margin=0.2, device=device, seed=42,
+                                  outputs=outputs(), dtype="bf16")
+        tr.set_labels(torch.arange(batch) // 4)
+        xs = [synth.images(batch, 3, image, 1234 + s, device) for s in range(2)]
+        for i in range(warmup):
+            tr.step(xs[i % 2], None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = tr.step(xs[i % 2], None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[key] = {"triplets_per_s": round(batch / dt, 1), "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                    "warmup": warmup, "dtype": "bf16 operands / activations, fp32 accumulate + master weights",
+                    "step_mfma_roofline_frac": round(batch / dt * flop / (PEAK_BF16_MFMA_TFLOPS * 1e12), 4), "peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                    "loss": round(float(loss.mean().item()), 6)}
+        del tr, xs
+        torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline(batch, image, torch):
@@ -348,6 +381,10 @@ def main():
             out["tuning"] = {"source": tuning_src, "table": {k: [v["tune_fwd"], v["tune_dgrad"], v["tune_wgrad"], int(v["wino_fwd"]), int(v["wino_dgrad"])]
                                                                for k, v in tr.plan.tuning_table().items()},
                              "columns": ["tune_fwd", "tune_dgrad", "tune_wgrad", "wino_fwd", "wino_dgrad"]}
+        if world == 1 and args.workload == "efm" and args.dtype == "f32" and not args.no_secondary:
+            del tr
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_configs(torch, device, args.image)
         if world == 1 and not args.no_cpu_baseline and args.workload == "efm" and args.dtype == "f32":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.image, torch)
         print(json.dumps(out), flush=True)

@@ -92,16 +92,16 @@ def test_convb_fused_epilogue(ways, pool, out_f32):
     assert rel_err(from_nhwc(dy, cout), bf(dy_ref)) < 1e-6
 
 
-@pytest.mark.parametrize("net", ["lightcnn9", "deepcnn"])
-def test_mfm2_stack_bf16_step_vs_emulation(net):
+@pytest.mark.parametrize("net,batch,image", [("lightcnn9", 16, 32), ("deepcnn", 16, 32), ("lightcnn9", 8, 112), ("deepcnn", 8, 112)])
+def test_mfm2_stack_bf16_step_vs_emulation(net, batch, image):
     """Whole mining step in bf16 — LightCNN-9 (BASELINE configs[2]) and the deeper 512-d CNN (configs[4]) — against the torch-CPU
     emulation of the same rounding points (fp64 in between).  Free-running, device and emulation decorrelate to the bf16 noise
     level after a few layers (see the oracle's docstring), so the tight comparison is teacher-forced: every emulated layer
-    starts from the device's stored activation."""
+    starts from the device's stored activation.  Run at 32x32 and at the BASELINE geometry 3x112x112 (every real grid shape of the
+    layers, the 7x7x128 -> 512 fc, floor pooling 7 -> 3 does not occur: 112 -> 56 -> 28 -> 14 -> 7)."""
     from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol
     from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
     from oracle import efm_oracle_torch as OT
-    batch, image = 16, 32
     outputs, fwd = ((efm_symbol.lightcnn9_embedding_net(), OT.lightcnn9_forward_bf16) if net == "lightcnn9"
                     else (efm_symbol.deepcnn_embedding_net(), OT.deepcnn_forward_bf16))
     tr = MiningTripletTrainer(batch, image=image, outputs=outputs, seed=7, dtype="bf16")
@@ -154,7 +154,7 @@ def test_mfm2_stack_bf16_step_vs_emulation(net):
     tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
     g = tr.plan.export_params(tr.grad)
     errs = {k: rel_err(g[k].cpu().numpy().reshape(tp[k].shape), tp[k].grad.numpy()) for k in tp}
-    print("bf16 %s: free-running emb %.2e; teacher-forced gradient worst %.2e" % (net, e_free, max(errs.values())))
+    print("bf16 %s B=%d %dx%d: free-running emb %.2e; teacher-forced gradient worst %.2e" % (net, batch, image, image, e_free, max(errs.values())))
     # ~1e-5 at fc1, growing towards the input: a one-ulp difference in a bf16-stored gradient spreads over the 9*cin inputs of the
     # next data-gradient, some of which cross their own rounding boundary, ... until the difference saturates at the bf16 noise of
     # the gradients themselves (2.5e-3 over LightCNN-9's 10 layers, 1.2e-2 over the deeper CNN's 14).  A wiring or rounding-point
@@ -235,3 +235,55 @@ def test_efm29_bf16_step_vs_emulation():
     assert min(cos.values()) > 0.9, cos
     assert torch.isfinite(tr.grad).all()
     tr.update()
+
+
+@pytest.mark.parametrize("net,batch", [("lightcnn9", 512), ("deepcnn", 128)])
+def test_bf16_full_size_properties(net, batch):
+    """BASELINE configs[2] (LightCNN-9, 512 images of 3x112x112, bf16, semi-hard mining on) and configs[4] (deeper CNN, 128 images)
+    at their FULL sizes — properties that need no oracle run:
+    (a) a batch permutation permutes the embeddings bit for bit;  (b) the step is bitwise reproducible;
+    (c) scaling the upstream gradient by 2 scales every gradient by exactly 2 (power-of-two scaling commutes with every bf16 / fp32
+        rounding on the way);  (d) the gradient of the batch = the sum of the gradients of its two halves (data-parallel contract;
+        fp32 accumulation order only);  (e) the semi-hard miner returns a different-identity row for every anchor and the mined
+        step's loss and gradients are finite."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import efm_symbol, synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import MiningTripletTrainer
+    image = 112
+    mk = efm_symbol.lightcnn9_embedding_net if net == "lightcnn9" else efm_symbol.deepcnn_embedding_net
+    tr = MiningTripletTrainer(batch, image=image, outputs=mk(), seed=42, dtype="bf16")
+    labels = (np.arange(batch) // 4).astype(np.int32)
+    tr.set_labels(labels)
+    x = synth.images(batch, 3, image, 1234)
+    emb, _ = tr.plan.forward(x, tr.flat, train=False)
+    emb = emb.clone()
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(0)).cuda()
+    emb_p, _ = tr.plan.forward(x[perm].contiguous(), tr.flat, train=False)
+    assert torch.equal(emb_p, emb[perm])                                                    # (a)
+    assert torch.isfinite(emb).all() and float((emb.norm(dim=1) - 1).abs().max()) < 1e-3
+    d = emb.shape[1]
+    demb = (synth.uniform01(batch * d, 77).view(batch, d) * 2 - 1).contiguous()
+
+    def grad_of(scale):
+        tr.plan.forward(x, tr.flat, train=True)
+        tr.plan.backward([demb * scale, None], tr.flat, tr.grad)
+        return tr.grad.clone()
+    g1 = grad_of(1.0)
+    assert torch.equal(g1, grad_of(1.0))                                                    # (b)
+    assert torch.equal(grad_of(2.0), 2 * g1)                                                # (c)
+    half = batch // 2
+    th = MiningTripletTrainer(half, image=image, outputs=mk(), seed=42, dtype="bf16")
+    th.flat.copy_(tr.flat)
+    gsum = torch.zeros_like(g1)
+    for sidx in range(2):
+        rows = slice(sidx * half, (sidx + 1) * half)
+        th.plan.forward(x[rows].contiguous(), th.flat, train=True)
+        th.plan.backward([demb[rows].contiguous(), None], th.flat, th.grad)
+        gsum += th.grad
+    e_sum = rel_err(gsum.cpu().numpy(), g1.cpu().numpy())
+    assert e_sum < 1e-4, e_sum                                                              # (d)
+    loss = tr.forward_loss(x)                                                               # (e) mining on
+    neg = tr.last["neg"].cpu().numpy()
+    assert (neg >= 0).all() and (labels[neg] != labels).all()
+    tr.backward()
+    assert torch.isfinite(loss).all() and torch.isfinite(tr.grad).all() and float(tr.grad.abs().max()) > 0
+    print("bf16 %s full size B=%d: shard-sum rel err %.2e, mean loss %.4f" % (net, batch, e_sum, float(loss.mean())))
