@@ -68,13 +68,14 @@ def kernel_families(trainer, torch, iters=3, only=None, dedup=True):
         e1.synchronize()
         return e0.elapsed_time(e1) / iters
 
-    def add(name, key, run, alg, exe):
+    def add(name, key, run, alg, exe, nbytes=0.0):
         if only is not None and not name.startswith(only):  # tools/family_probe.py: just this kernel instance (rocprofv3 --pmc passes)
             return
         if key not in cache or not dedup:  # dedup=False (profiling probe): launch mix = the step's, repeated shapes included
             cache[key] = timed(run)
-        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "alg_flop": 0.0, "mfma_flop": 0.0})
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "alg_flop": 0.0, "mfma_flop": 0.0, "alg_bytes": 0.0})
         f["launches"] += 1
+        f["alg_bytes"] += nbytes
         f["ms"] += cache[key]
         f["alg_flop"] += alg
         f["mfma_flop"] += exe
@@ -93,36 +94,45 @@ def kernel_families(trainer, torch, iters=3, only=None, dedup=True):
         w = torch.rand((d.n_pad16, d.k_pad), device=dev)
         b = torch.zeros(d.n_pad16, device=dev)
         e = st.epi
+        # algorithmic HBM bytes of a launch: every operand once (fp32): input + output (+ route bytes of a fused epilogue) + weights
+        xb, yb, wb_ = 4.0 * d.batch * d.hin * d.win * d.cin_p, 4.0 * d.batch * d.hout * d.wout * d.cout_p, 4.0 * d.n_pad16 * d.k_pad
+        if e is not None:
+            co = ops.mfm_out_channels(d.cout, e["ways"])
+            cop = (co + 3) & ~3
+            zpix = d.batch * ((d.hout // 2) * (d.wout // 2) if e["pool"] else d.hout * d.wout)
+            fwd_bytes = xb + wb_ + zpix * cop * 5.0
+        else:
+            fwd_bytes = xb + wb_ + yb
         if e is not None:
             if getattr(st, "wino_fwd", False):
                 u = ops.wino_mfm_make_u(d, w, e["ways"])
                 name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_FUSED, e["ways"], e["pool"])
-                add(name, ("f",) + shape, lambda: ops.wino_mfm_fwd(d, x, u, b, e["ways"], e["order"], e["pool"]), alg, exe)
+                add(name, ("f",) + shape, lambda: ops.wino_mfm_fwd(d, x, u, b, e["ways"], e["order"], e["pool"]), alg, exe, fwd_bytes)
             else:
                 name, exe = ops.conv_kernel_info(d, ops.PASS_FUSED, e["ways"], e["pool"])
-                add(name, ("f",) + shape, lambda: ops.conv_mfm_fwd(d, x, w, b, e["ways"], e["order"], e["pool"]), alg, exe)
+                add(name, ("f",) + shape, lambda: ops.conv_mfm_fwd(d, x, w, b, e["ways"], e["order"], e["pool"]), alg, exe, fwd_bytes)
         else:
             y = torch.empty_like(dy)
             if getattr(st, "wino_fwd", False):
                 u = ops.wino_make_u(d, w)
                 name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_FWD)
-                add(name, ("f",) + shape, lambda: ops.wino_fwd(d, x, u, b, out=y), alg, exe)
+                add(name, ("f",) + shape, lambda: ops.wino_fwd(d, x, u, b, out=y), alg, exe, fwd_bytes)
             else:
                 name, exe = ops.conv_kernel_info(d, ops.PASS_FWD)
-                add(name, ("f",) + shape, lambda: ops.conv_fwd(d, x, w, b, out=y), alg, exe)
+                add(name, ("f",) + shape, lambda: ops.conv_fwd(d, x, w, b, out=y), alg, exe, fwd_bytes)
         if st.inputs[0].needs_grad:
             dx = torch.empty_like(x)
             if getattr(st, "wino_dgrad", False):
                 u = ops.wino_make_u(d, w, dgrad=True)
                 name, exe = ops.conv_kernel_info(d, ops.PASS_WINO_DGRAD)
-                add(name, ("d",) + shape, lambda: ops.wino_bwd_data(d, dy, u, out=dx), alg, exe)
+                add(name, ("d",) + shape, lambda: ops.wino_bwd_data(d, dy, u, out=dx), alg, exe, xb + yb + wb_)
             else:
                 wd = torch.rand((d.dn_pad16, d.dk_pad), device=dev)
                 name, exe = ops.conv_kernel_info(d, ops.PASS_DGRAD)
-                add(name, ("d",) + shape, lambda: ops.conv_bwd_data(d, dy, wd, out=dx), alg, exe)
+                add(name, ("d",) + shape, lambda: ops.conv_bwd_data(d, dy, wd, out=dx), alg, exe, xb + yb + wb_)
         dw, db = torch.empty_like(w), torch.empty_like(b)
         name, exe = ops.conv_kernel_info(d, ops.PASS_WGRAD)
-        add(name + " (+ wgrad_reduce_k)", ("w",) + shape, lambda: ops.conv_bwd_weight(d, x, dy, dw=dw, dbias=db), alg, exe)
+        add(name + " (+ wgrad_reduce_k)", ("w",) + shape, lambda: ops.conv_bwd_weight(d, x, dy, dw=dw, dbias=db), alg, exe, xb + yb + wb_)
         del x, dy, w
     return fam
 
@@ -156,6 +166,7 @@ def dominant_kernel_roofline(trainer, torch, iters=3):
             "traffic": traffic, "flop_per_launch": top["alg_flop"] / top["launches"], "ms_per_launch": round(top["ms"] / top["launches"], 4),
             "launches_per_step": top["launches"], "ms_per_step": round(top["ms"], 3),
             "mfma_flop_executed": top["mfma_flop"] / top["launches"],
+            "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
             "mfma_busy_frac": round(top["mfma_flop"] / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "note": "frac = ALGORITHMIC direct-convolution flops / time / peak; a Winograd F(2x2,3x3) kernel executes 2.25x fewer multiplies "
                     "for them, so mfma_busy_frac (executed matrix-core flops / time / peak) is the utilisation of the matrix pipe",
