@@ -32,7 +32,7 @@ constexpr int V_STAGE = 16 * TB * KC;  // floats: V[xi][row][8], row = tile ^ ((
 
 struct WinoP {
   const float* x;
-  const float* u;     // [channel block][16 xi][NB rows][kpad]
+  const float* u;     // [channel block][K chunk][16 xi][NB rows][KC]  (chunk-major: wino_u_k)
   const float* bias;  // may be null
   const float* res;   // may be null: added to y (residual / skip gradient)
   float* y;
@@ -230,10 +230,10 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
       xoff[rr] = ok ? (unsigned)((((b * p.h + iy) * p.w + ix) * p.cin_p + q * 4) * 4) : EFM_OOB;
     }
   }
-  // ---- U staging: a wave issues NTB LDS-DMA instructions per chunk, each 32 consecutive rows of this block's [16 xi][NB] x 2 pieces
-  const unsigned ubase = (unsigned)(((((nb * 16 * NB) + 32 * wave * NTB + (lane >> 1)) * p.kpad) + (lane & 1) * 4) * 4);
-  const unsigned ustep = (unsigned)(32 * p.kpad * 4);
-
+  // ---- U staging: the block's slice of chunk ch is 16*NB*KC consecutive floats of U (chunk-major layout, wino_u_k) in the order of
+  // the LDS stage; a wave issues NTB LDS-DMA instructions per chunk, each 1 KiB of consecutive bytes
+  const unsigned ubase = (unsigned)(((long)nb * p.chunks * 16 * NB * KC + wave * NTB * 256 + lane * 4) * 4);
+  const unsigned uchunk = (unsigned)(16 * NB * KC * 4);
   u32x4 xreg[4];
   auto load_x = [&](int ch) {
     const bool cok = ch * KC + q * 4 < p.cin_p;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
 #pragma unroll
     for (int j = 0; j < NTB; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Us + (wave * NTB + j) * 256), 16,
-                                               ubase + (unsigned)j * ustep + (unsigned)(ch * KC * 4), 0, 0, 0);
+                                               ubase + (unsigned)ch * uchunk + (unsigned)(j * 1024), 0, 0, 0);
   };
   // B^T d B for 4 channels; this lane ends with column j = c of every row i and stores V[4i + c][tt][4q..4q+3]
   auto transform = [&](int buf) {
@@ -386,9 +386,9 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
       xoff[rr] = ok ? (unsigned)((((b * p.h + iy) * p.w + ix) * p.cin_p) * 4) : EFM_OOB;
     }
   }
-  // U staging: NTB LDS-DMA instructions per wave and chunk, each 64 consecutive rows of this block's [16 xi][NB] x 16 bytes
-  const unsigned ubase = (unsigned)((((nb * 16 * NB) + 64 * wi * NTB + lane) * p.kpad) * 4);
-  const unsigned ustep = (unsigned)(64 * p.kpad * 4);
+  // U staging: NTB LDS-DMA instructions per wave and chunk, each 1 KiB of consecutive bytes of the block's chunk slice (chunk-major U)
+  const unsigned ubase = (unsigned)(((long)nb * p.chunks * 16 * NB * KC4 + wi * NTB * 256 + lane * 4) * 4);
+  const unsigned uchunk = (unsigned)(16 * NB * KC4 * 4);
 
   u32x4 xreg[4];
   auto load_x = [&](int ch) {
@@ -401,7 +401,7 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
 #pragma unroll
     for (int j = 0; j < NTB; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (__attribute__((address_space(3))) void*)(Us + (wi * NTB + j) * 256), 16,
-                                               ubase + (unsigned)j * ustep + (unsigned)(ch * KC4 * 4), 0, 0, 0);
+                                               ubase + (unsigned)ch * uchunk + (unsigned)(j * 1024), 0, 0, 0);
   };
   auto transform = [&](int buf) {
     float* Vs = smem + buf * STAGE;
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(256, 2) wino4_k(const WinoP p) {
 // fused-epilogue forward (ways > 0): row r of channel block blk is output channel slice*cs + blk*cn + r % cnb, slice = r / cnb
 // (every slice of a channel in one block), rows past the last slice are zero.
 __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin, int k_pad_src,
-                                                int cin_p, int n_rows, int nbr, int kpad, int ways, int cn) {
+                                                int cin_p, int n_rows, int nbr, int kpad, int ways, int cn, int kc) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)n_rows * kpad) return;
   const int nrow = (int)(i / kpad), k = (int)(i - (long)nrow * kpad);
@@ -527,9 +527,13 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
     t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
     t[3][b] = g[2][b];
   }
+  // chunk-major: U[channel block][K chunk of kc][16 xi][nbr rows][kc] — the 16 planes of one chunk of one block are ONE contiguous
+  // run (16*nbr*kc floats), in exactly the order of the kernels' LDS stage, so an LDS-DMA wave instruction copies 1 KiB of
+  // consecutive bytes (8 cache lines) instead of 16- / 32-byte pieces of 32-64 different rows (lines) of a [row][kpad] matrix.
   const int blk = nrow / nbr, row = nrow - blk * nbr;
-  float* dst = u + ((long)blk * 16 * nbr + row) * kpad + k;
-  const long plane = (long)nbr * kpad;
+  const int chn = k / kc, kk = k - chn * kc;
+  float* dst = u + (((long)blk * (kpad / kc) + chn) * 16 * nbr + row) * kc + kk;
+  const long plane = (long)nbr * kc;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     dst[(4 * a + 0) * plane] = t[a][0];
@@ -894,7 +898,7 @@ int efm_wino_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int
   const WinoPlan pl = dgrad ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd);
   const long total = (long)pl.n_rows * pl.kpad;
   hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, dgrad ? 1 : 0, d->cout,
-                     d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, 0, 0);
+                     d->cin, d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, 0, 0, pl.variant == 4 ? KC4 : KC);
   return efm::check_launch("wino_make_u");
 }
 
@@ -910,7 +914,7 @@ int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u,
   const WinoPlan pl = plan_wino(d->cin_p, d->cout, d->tune_fwd, ways);
   const long total = (long)pl.n_rows * pl.kpad;
   hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, 0, d->cout, d->cin,
-                     d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, ways, pl.cn);
+                     d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, ways, pl.cn, pl.variant == 4 ? KC4 : KC);
   return efm::check_launch("wino_mfm_make_u");
 }
 
