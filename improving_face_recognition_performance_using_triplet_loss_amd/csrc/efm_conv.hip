@@ -578,6 +578,15 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   // possible count, fully unrolled and branch-free inside (a per-tile branch costs more than the MFMA it saves); the count is
   // wave-uniform, so picking the loop is one scalar branch per 16-pixel step.
   const int nkw = (nkt > wave) ? (nkt - wave + 3) / 4 : 0;
+  // Bias gradient = column sums of dy: the dy fragments pass through the registers of every wave anyway, so wave 0 of the first
+  // k-block adds them up on the side (NTW v_add per 4-pixel step, in the shadow of KPW*NTW MFMAs) — no second pass over dy, no
+  // column-sum blocks competing for the CUs.  One partial per pixel split, reduced in fixed order by wgrad_reduce_k.
+  // The n-tiles are dealt to the 4 waves (wave w sums tiles w, w+4, ...): (NTW+3)/4 registers and adds per wave instead of NTW in one.
+  constexpr int NB4 = (NTW + 3) / 4;
+  const bool do_bias = p.bias_part != nullptr && kb == 0;
+  float bsum[NB4];
+#pragma unroll
+  for (int j = 0; j < NB4; ++j) bsum[j] = 0.f;
   auto compute = [&](auto nk_tag, int buf) {
     constexpr int NK = decltype(nk_tag)::value;
     const float* Xs = smem + buf * TILE;
@@ -597,16 +606,43 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
     }
   };
 
+  // column sums of the 16-pixel dy tile, after the MFMAs of the step (its own pass over LDS: 4*NB4 ds_reads per wave, only in the
+  // k-block-0 blocks; kept out of the unrolled MFMA region, where the registers are scarcest)
+  auto bias_acc = [&](int buf) {
+    const float* Ys = smem + buf * TILE + BP * BKR;
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      const int nt = wave + 4 * j, ntc = nt < NTW ? nt : NTW - 1;
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < BP / 4; ++s) v += Ys[(4 * s + fq) * BNW + (SWZ_Y ? ((ntc * 16 + fi) ^ fx) : (ntc * 16 + fi))];
+      bsum[j] += nt < NTW ? v : 0.f;
+    }
+  };
+
   const int steps = (m_end - m_begin + BP - 1) / BP;
   if (steps > 0) load_tile(0, 0);
   __syncthreads();
   for (int t = 0; t < steps; ++t) {
     if (t + 1 < steps) load_tile(t + 1, (t + 1) & 1);
+    // one scalar branch per 16-pixel step picks the fully unrolled loop for this wave's tile count (wave 0, the bias wave, always
+    // owns the block's first k-tile)
     if (nkw == KPW)
       compute(std::integral_constant<int, KPW>{}, t & 1);
     else if (KPW == 2 && nkw == 1)
       compute(std::integral_constant<int, 1>{}, t & 1);
+    if (do_bias) bias_acc(t & 1);
     __syncthreads();  // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences the reads of tile t
+  }
+  if (do_bias) {  // lane (fi, fq) holds the sums of pixels == fq (mod 4): add the four pixel groups, lanes fq == 0 store
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      const int nt = wave + 4 * j;
+      float v = bsum[j];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (fq == 0 && nt < nnt) p.bias_part[(long)split * p.n_pad16 + n0 + nt * 16 + fi] = v;
+    }
   }
 
   float* ws = p.ws + (long)split * p.n_pad16 * p.k_pad;
@@ -958,7 +994,7 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.groups = 1;
   pl.slab_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad;
   pl.lvl2_floats = 0;
-  pl.bias_chunks = (M + BIAS_ROWS - 1) / BIAS_ROWS;
+  pl.bias_chunks = pl.splits;  // one column-sum partial of dy per pixel split (written by the k-block-0 blocks)
   pl.bias_groups = 0;
   pl.ws_floats = pl.slab_floats + (size_t)pl.bias_chunks * d->n_pad16;
   return pl;
@@ -1476,7 +1512,7 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   p.bias_part = dbias ? bpart : nullptr;
   p.ktiles = d->k_pad / 16; p.ntiles = d->n_pad16 / 16; p.bias_rows = BIAS_ROWS;
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
-  dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
+  dim3 grid((unsigned)p.mma_blocks);  // the bias gradient rides in the k-block-0 blocks: no column-sum blocks
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
   if (rc != EFM_OK) return rc;
   rc = efm::check_launch("conv_wgrad");

@@ -1,7 +1,10 @@
-# A/B of two builds on the same box: tools/ab/libefm_old.so (EFM_LIB_PATH) vs the in-tree library.
+# A/B of two builds on the same box: tools/ab/libefm_old.so (EFM_LIB_PATH) vs the in-tree library, weight gradient per layer.
 set -o pipefail
 mkdir -p gpurun_out/ab
-for CFG in "0 0" "3840 1" "2560 2"; do
+rm -f gpurun_out/ab/wgrad.txt
+python -m pytest tests/test_kernels_gpu.py -x -q -k "wgrad or conv or bias" > gpurun_out/ab/wgrad_tests.log 2>&1 || { tail -30 gpurun_out/ab/wgrad_tests.log; exit 1; }
+tail -2 gpurun_out/ab/wgrad_tests.log
+for CFG in "0 0" "3840 1"; do
   set -- $CFG
   for L in old new; do
     if [ $L = old ]; then export EFM_LIB_PATH=$PWD/tools/ab/libefm_old.so; else unset EFM_LIB_PATH; fi
