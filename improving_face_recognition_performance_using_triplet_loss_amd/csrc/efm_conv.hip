@@ -1649,12 +1649,106 @@ int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t*
   return efm::check_launch("convb_mfm_fwd");
 }
 
+}  // extern "C"
+
+namespace {
+// Vector form of mfm_pool_bwd_k for bf16 gradients whose slice width is a multiple of 8 channels (every MFM2 / MFM3 layer of
+// LightCNN-9, the deeper CNN and most of EFM-29's bf16 plan): thread = (pooling window | pixel, group of 8 channels): one 8-byte
+// route load and one 16-byte (bf16) / 32-byte (fp32) dz load per slice-half, then a 16-byte store per (window pixel, slice) —
+// the scalar kernel's 2-byte stores ran this pure streaming kernel at ~1 TB/s.  Same arithmetic, same bits.
+__device__ __forceinline__ void load8(const __bf16* p, float* out) {  // 16-byte aligned
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[e] = (float)v[e];
+}
+__device__ __forceinline__ void load8(const float* p, float* out) {  // 16-byte aligned (32 bytes in two pieces)
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { out[e] = a[e]; out[4 + e] = b[e]; }
+}
+
+template <typename TZ>
+__global__ void __launch_bounds__(256) mfm_pool_bwd_v8_k(const unsigned char* __restrict__ route, const TZ* __restrict__ dz,
+                                                         __bf16* __restrict__ dy, long items, int h, int w, int c, int ways, int pool,
+                                                         int cp, int cpo) {
+  const int cs = c / ways, g8 = cs >> 3;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= items * g8) return;
+  const long it = i / g8;
+  const int j = (int)(i - it * g8) * 8;
+  float gmax[8], gmin[8];
+  unsigned char rmax[8], rmin[8];
+  auto load = [&](long q) {
+    const uint2 r = *reinterpret_cast<const uint2*>(route + q * cpo + j);
+    *reinterpret_cast<uint2*>(rmax) = r;
+    load8(dz + q * cpo + j, gmax);
+    if (ways == 3) {
+      *reinterpret_cast<uint2*>(rmin) = *reinterpret_cast<const uint2*>(route + q * cpo + cs + j);
+      load8(dz + q * cpo + cs + j, gmin);
+    }
+  };
+  const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  if (!pool) {
+    load(it);
+    __bf16* d = dy + it * cp;
+    for (int sl = 0; sl < ways; ++sl) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (rmax[e] == sl) ? gmax[e] : 0.f;
+        if (ways == 3 && rmin[e] == sl) v += gmin[e];
+        o[e] = (__bf16)v;
+      }
+      *reinterpret_cast<bf16x8*>(d + sl * cs + j) = o;
+    }
+    return;
+  }
+  const int hg = (h + 1) >> 1, wg = (w + 1) >> 1, hp = h >> 1, wp = w >> 1;
+  const int wq = (int)(it % wg);
+  const long t = it / wg;
+  const int hq = (int)(t % hg);
+  const long b = t / hg;
+  const bool full = hq < hp && wq < wp;
+  if (full) load((b * hp + hq) * wp + wq);
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    const int hh = 2 * hq + (px >> 1), ww = 2 * wq + (px & 1);
+    if (hh >= h || ww >= w) continue;
+    __bf16* d = dy + ((b * h + hh) * w + ww) * cp;
+    for (int sl = 0; sl < ways; ++sl) {
+      bf16x8 o = zero;
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = (rmax[e] == px * 4 + sl) ? gmax[e] : 0.f;
+          if (ways == 3 && rmin[e] == px * 4 + sl) v += gmin[e];
+          o[e] = (__bf16)v;
+        }
+      }
+      *reinterpret_cast<bf16x8*>(d + sl * cs + j) = o;
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+
 int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f32, uint16_t* dy, int batch, int h, int w, int c, int ways,
                            int pool, void* stream) {
   EFM_REQUIRE(route && dz && dy && batch > 0 && h > 0 && w > 0, "convb_mfm_pool_bwd: bad argument");
   EFM_REQUIRE((ways == 2 || ways == 3) && c % ways == 0, "convb_mfm_pool_bwd: c=%d not divisible by ways=%d", c, ways);
   const int cs = c / ways, cp = pad8(c), cw = cs + (cp - c), co = (ways == 3) ? 2 * cs : cs;
   const long items = pool ? (long)batch * ((h + 1) / 2) * ((w + 1) / 2) : (long)batch * h * w;
+  if (cs % 8 == 0 && env_int("EFM_POOLBWD_V8", 1)) {  // c = ways*cs is then a multiple of 8 too: no pad channels, 16-byte stores
+    dim3 gv((unsigned)efm::cdiv(items * (cs / 8), 256));
+    if (dz_f32)
+      hipLaunchKernelGGL((mfm_pool_bwd_v8_k<float>), gv, dim3(256), 0, (hipStream_t)stream, route, (const float*)dz,
+                         reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cp, efm_pad4(co));
+    else
+      hipLaunchKernelGGL((mfm_pool_bwd_v8_k<__bf16>), gv, dim3(256), 0, (hipStream_t)stream, route, (const __bf16*)dz,
+                         reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cp, pad8(co));
+    return efm::check_launch("convb_mfm_pool_bwd");
+  }
   dim3 grid((unsigned)efm::cdiv(items * cw, 256));
   if (dz_f32)
     hipLaunchKernelGGL((mfm_pool_bwd_k<float, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, route, (const float*)dz,
