@@ -54,7 +54,7 @@ def main(argv=None):
         rec, lst = os.path.join(args.root, name + ".rec"), os.path.join(args.root, name + ".lst")
         if not args.synthetic and os.path.exists(rec):
             it = mxio.ImageRecordIter(path_imgrec=rec, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True, data_shape=shape,
-                                      batch_size=batch_size, seed=seed)
+                                      batch_size=batch_size, seed=seed, device=torch.device("cuda", 0))
             return it, (len(open(lst).readlines()) if os.path.exists(lst) else len(it))
         if not args.synthetic:
             raise SystemExit("no %s found — pass --synthetic N" % rec)

@@ -191,6 +191,41 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_k(const float* __restrict__ 
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// ImageRecordIter's augmentation on the device: decoded uint8 HWC images -> random / centre crop, horizontal mirror, * scale,
+// NCHW fp32 (what the iterator emits, ref: train_efm.py:179-181 `scale=1./255, rand_crop=True, rand_mirror=True`).
+// One thread per output element; reads are byte gathers from a window of the source image (L2-resident), writes are coalesced.
+__global__ void __launch_bounds__(256) crop_mirror_u8_k(const unsigned char* __restrict__ src, const int* __restrict__ crop,
+                                                        float* __restrict__ dst, long total, int ih, int iw, int c, int h, int w,
+                                                        float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % w);
+  long t = i / w;
+  const int yo = (int)(t % h);
+  t /= h;
+  const int ch = (int)(t % c);
+  const long b = t / c;
+  const int y0 = crop[b * 3], x0 = crop[b * 3 + 1], flip = crop[b * 3 + 2];
+  const int xs = x0 + (flip ? (w - 1 - xo) : xo);
+  dst[i] = (float)src[((b * ih + (y0 + yo)) * iw + xs) * c + ch] * scale;
+}
+}  // namespace
+
+extern "C" {
+
+int efm_crop_mirror_u8(const uint8_t* src_hwc, const int32_t* crop, float* dst_nchw, int batch, int ih, int iw, int c, int h, int w,
+                       float scale, void* stream) {
+  EFM_REQUIRE(src_hwc && crop && dst_nchw && batch > 0 && c > 0 && h > 0 && w > 0 && ih >= h && iw >= w,
+              "crop_mirror_u8: bad argument (the crop window must fit the source image)");
+  const long total = (long)batch * c * h * w;
+  hipLaunchKernelGGL(crop_mirror_u8_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src_hwc, crop, dst_nchw,
+                     total, ih, iw, c, h, w, scale);
+  return efm::check_launch("crop_mirror_u8");
+}
+
 int efm_nchw_to_nhwc(const float* x, float* y, int batch, int c, int h, int w, void* stream) {
   EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc: bad argument");
   const int cp = efm_pad4(c);

@@ -219,7 +219,7 @@ class ImageRecordIter:
     set once however many ranks read it."""
 
     def __init__(self, path_imgrec, data_shape, batch_size, scale=1.0, rand_crop=False, rand_mirror=False, shuffle=False, seed=0,
-                 part_index=0, num_parts=1, **_):
+                 part_index=0, num_parts=1, device=None, **_):
         if not 0 <= part_index < num_parts:
             raise ValueError("part_index %d outside [0, %d)" % (part_index, num_parts))
         self.path, self.data_shape, self.batch_size, self.scale = path_imgrec, tuple(data_shape), batch_size, scale
@@ -229,6 +229,9 @@ class ImageRecordIter:
         self.index = index[part_index * n // num_parts: (part_index + 1) * n // num_parts]   # contiguous chunk, like MXNet's partition
         self.num_total = n
         self._rng = np.random.default_rng(seed)
+        # device: crop / mirror / scale / uint8 -> fp32 run on the GPU (efm_crop_mirror_u8) and the batch is born there: the host only
+        # decodes, and 4x fewer bytes cross PCIe.  Same random draws in the same order as the host path: bit-identical batches.
+        self.device = device
         self._file = None
         self._order = np.arange(len(self.index))
         self.epoch = -1
@@ -241,7 +244,7 @@ class ImageRecordIter:
         self.reset()
         return self
 
-    def _decode(self, k):
+    def _read(self, k):
         c, h, w = self.data_shape
         label, _, img = unpack_img(read_record_at(self._file, *self.index[k]), gray=(c == 1))
         ih, iw = img.shape[:2]
@@ -249,10 +252,16 @@ class ImageRecordIter:
             raise ValueError("record image %dx%d smaller than data_shape %dx%d" % (ih, iw, h, w))
         y0 = int(self._rng.integers(0, ih - h + 1)) if self.rand_crop else (ih - h) // 2
         x0 = int(self._rng.integers(0, iw - w + 1)) if self.rand_crop else (iw - w) // 2
+        flip = bool(self.rand_mirror and self._rng.random() < 0.5)
+        return img, (y0, x0, flip), float(np.atleast_1d(label)[0])
+
+    def _decode(self, k):
+        c, h, w = self.data_shape
+        img, (y0, x0, flip), label = self._read(k)
         img = img[y0:y0 + h, x0:x0 + w]
-        if self.rand_mirror and self._rng.random() < 0.5:
+        if flip:
             img = img[:, ::-1]
-        return (img[None] if c == 1 else img.transpose(2, 0, 1)), float(np.atleast_1d(label)[0])
+        return (img[None] if c == 1 else img.transpose(2, 0, 1)), label
 
     def __next__(self):
         import torch
@@ -263,14 +272,32 @@ class ImageRecordIter:
         if self._file is None:
             self._file = open(self.path, "rb")
         c, h, w = self.data_shape
-        data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)
         labels = np.empty((self.batch_size,), dtype=np.float32)
-        for j in range(self.batch_size):
-            data[j], labels[j] = self._decode(int(self._order[self.pos + j]))
+        if self.device is not None:
+            imgs, crops = [], np.empty((self.batch_size, 3), dtype=np.int32)
+            for j in range(self.batch_size):
+                img, crops[j], labels[j] = self._read(int(self._order[self.pos + j]))
+                imgs.append(img if img.ndim == 3 else img[:, :, None])
+            if len({im.shape for im in imgs}) == 1:      # one source size per batch (the usual pre-resized .rec): the GPU path
+                from . import ops
+                self.pos += self.batch_size
+                src = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
+                x = ops.crop_mirror_u8(src, torch.from_numpy(crops).to(self.device, non_blocking=True), h, w, self.scale)
+                return Batch(["data"], [x], ["softmax_label"], [torch.from_numpy(labels)])
+            data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)   # mixed sizes: crop on the host, same draws
+            for j, (im, (y0, x0, flip)) in enumerate(zip(imgs, crops)):
+                im = im[y0:y0 + h, x0:x0 + w]
+                data[j] = (im[:, ::-1] if flip else im).transpose(2, 0, 1)
+        else:
+            data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)
+            for j in range(self.batch_size):
+                data[j], labels[j] = self._decode(int(self._order[self.pos + j]))
         self.pos += self.batch_size
         x = torch.from_numpy(data).to(torch.float32)
         if self.scale != 1.0:
             x *= self.scale
+        if self.device is not None:
+            x = x.to(self.device)
         return Batch(["data"], [x], ["softmax_label"], [torch.from_numpy(labels)])
 
     next = __next__

@@ -156,6 +156,19 @@ def nchw_to_nhwc(x, out=None):
     return out
 
 
+def crop_mirror_u8(src, crop, h, w, scale=1.0):
+    """ImageRecordIter's crop / mirror / scale on the device: src uint8 (B, IH, IW, C) device tensor, crop int32 (B, 3) = (y0, x0,
+    mirror) device tensor -> fp32 NCHW (B, C, h, w)."""
+    _need_dev(crop)
+    if src.dtype != torch.uint8 or not src.is_cuda or not src.is_contiguous():
+        raise _lib.EfmError("crop_mirror_u8 needs a contiguous uint8 device tensor")
+    b, ih, iw, c = src.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=src.device)
+    check(_lib.load().efm_crop_mirror_u8(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(crop.data_ptr()), _p(out), b, ih, iw, c, h, w,
+                                         float(scale), _stream()), "efm_crop_mirror_u8")
+    return out
+
+
 def nhwc_to_nchw(x, c, out=None):
     _need_dev(x, out)
     b, h, w, cp = x.shape

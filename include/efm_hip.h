@@ -161,6 +161,11 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
  * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).
  * ------------------------------------------------------------------------------------ */
 int efm_nchw_to_nhwc(const float* x_nchw, float* y_nhwc, int batch, int c, int h, int w, void* stream);
+/* mx.io.ImageRecordIter's augmentation on the device (ref: train_efm.py:179-181: scale=1./255, rand_crop, rand_mirror): decoded uint8
+ * images src[b][ih][iw][c] (HWC, as an image decoder leaves them) -> dst[b][c][h][w] fp32 = scale * crop(mirror?(src)).
+ * crop[b] = (y0, x0, mirror 0/1), drawn by the caller (the host iterator); the window must fit: y0 + h <= ih, x0 + w <= iw. */
+int efm_crop_mirror_u8(const uint8_t* src_hwc, const int32_t* crop, float* dst_nchw, int batch, int ih, int iw, int c, int h, int w,
+                       float scale, void* stream);
 int efm_nhwc_to_nchw(const float* x_nhwc, float* y_nchw, int batch, int c, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -71,7 +71,7 @@ def main(argv=None):
         if path and os.path.exists(path):
             it = mxio.ImageRecordIter(path_imgrec=path, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True,
                                       data_shape=(Training_IMG_channel, Training_IMG_size, Training_IMG_size), batch_size=local_batch,
-                                      seed=seed + rank, part_index=rank, num_parts=world)   # each rank reads ITS share of the records
+                                      seed=seed + rank, part_index=rank, num_parts=world, device=devs)   # each rank reads ITS share of the records
             return it, it.num_total
         if not n:
             raise SystemExit("no RecordIO file given — pass --train-rec/--test-rec or --synthetic N")

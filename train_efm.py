@@ -65,7 +65,8 @@ def load_split(root, name, args, seed):
     if not args.synthetic and os.path.exists(rec):
         from improving_face_recognition_performance_using_triplet_loss_amd.mxio import ImageRecordIter
         it = ImageRecordIter(path_imgrec=rec, shuffle=True, scale=1. / 255, rand_crop=True, rand_mirror=True,
-                             data_shape=(args.channels, args.image_size, args.image_size), batch_size=args.batch_size, seed=seed)
+                             data_shape=(args.channels, args.image_size, args.image_size), batch_size=args.batch_size, seed=seed,
+                             device=torch.device("cuda", 0))   # crop / mirror / scale on the GPU
         lst = os.path.join(root, name + ".lst")
         n = len(open(lst).readlines()) if os.path.exists(lst) else len(it)
         return it, n
