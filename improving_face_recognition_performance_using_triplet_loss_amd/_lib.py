@@ -47,6 +47,8 @@ SIGNATURES = {
     "efm_mfm_pool_bwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
     "efm_conv_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
     "efm_conv_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "efm_conv_bwd_weight_slabs": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "efm_conv_bwd_weight_finish": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "efm_convb_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
     "efm_convb_dgrad_weight_elems": (c_size_t, [POINTER(ConvDesc)]),
     "efm_convb_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

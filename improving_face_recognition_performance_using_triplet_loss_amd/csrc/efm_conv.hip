@@ -473,6 +473,7 @@ struct WgradP {
   int mma_blocks;
   int ktiles, ntiles;  // 16-wide tiles of the packed gradient: k_pad / 16, n_pad16 / 16
   int bias_rows;       // dy rows per column-sum block
+  int dbg;             // EFM_WGRAD_DBG (measurement only): 1 = no operand loads, 2 = no MFMA loop
   unsigned x_bytes, y_bytes;
 };
 
@@ -621,10 +622,12 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   };
 
   const int steps = (m_end - m_begin + BP - 1) / BP;
-  if (steps > 0) load_tile(0, 0);
+  const bool dl = !(p.dbg & 1), dc = !(p.dbg & 2);
+  if (steps > 0 && dl) load_tile(0, 0);
   __syncthreads();
   for (int t = 0; t < steps; ++t) {
-    if (t + 1 < steps) load_tile(t + 1, (t + 1) & 1);
+    if (t + 1 < steps && dl) load_tile(t + 1, (t + 1) & 1);
+    if (!dc) { __syncthreads(); continue; }
     // one scalar branch per 16-pixel step picks the fully unrolled loop for this wave's tile count (wave 0, the bias wave, always
     // owns the block's first k-tile)
     if (nkw == KPW)
@@ -1276,7 +1279,7 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
   pl.NTW = round_nt((ntiles + nb - 1) / nb);
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
-  int splits = (env_int("EFM_WGRADB_BLOCKS", 1024) + base - 1) / base;
+  int splits = (env_int("EFM_WGRADB_BLOCKS", 512) + base - 1) / base;  // one round of resident blocks (2 per CU): measured best (sweep 256..4096)
   const int max_splits = std::min(1024, (M + 1023) / 1024);  // >= 32 contraction steps per block; > 32 slabs reduce in two levels
   splits = std::max(1, std::min(splits, max_splits));
   int mps = (M + splits - 1) / splits;
@@ -1486,9 +1489,12 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
                  d->kh, d->kw, d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, d->dk_pad, d->tune_dgrad, (hipStream_t)stream);
 }
 
-int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-  EFM_REQUIRE(d && x && dy && dw_packed, "conv_bwd_weight: null argument");
+// The weight gradient is two launches — the split-over-pixels matrix-core kernel that writes slabs (+ bias partials) into the
+// workspace, and the fixed-order reduction of those slabs — exposed separately so that a caller can put the reduction (pure
+// streaming work) on another stream, under the next layer's matrix-core kernel; efm_conv_bwd_weight runs both back to back.
+int efm_conv_bwd_weight_slabs(const efm_conv_desc* d, const float* x, const float* dy, int want_bias, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && dy, "conv_bwd_weight: null argument");
   EFM_REQUIRE_RANGE(d, 4, "conv_bwd_weight");
   const WgradPlan pl = plan_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
@@ -1507,21 +1513,40 @@ int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * sizeof(float));
   p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * d->cout_p * sizeof(float));
   float* slabs = (float*)workspace;
-  float* lvl2 = slabs + pl.slab_floats;
-  float* bpart = lvl2 + pl.lvl2_floats;
-  p.bias_part = dbias ? bpart : nullptr;
+  float* bpart = slabs + pl.slab_floats + pl.lvl2_floats;
+  p.bias_part = want_bias ? bpart : nullptr;
   p.ktiles = d->k_pad / 16; p.ntiles = d->n_pad16 / 16; p.bias_rows = BIAS_ROWS;
+  p.dbg = env_int("EFM_WGRAD_DBG", 0);
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
   dim3 grid((unsigned)p.mma_blocks);  // the bias gradient rides in the k-block-0 blocks: no column-sum blocks
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);
   if (rc != EFM_OK) return rc;
-  rc = efm::check_launch("conv_wgrad");
-  if (rc != EFM_OK) return rc;
+  return efm::check_launch("conv_wgrad");
+}
+
+int efm_conv_bwd_weight_finish(const efm_conv_desc* d, float* dw_packed, float* dbias, int accumulate, const void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && dw_packed, "conv_bwd_weight_finish: null argument");
+  const WgradPlan pl = plan_wgrad(d);
+  if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
+    efm::set_error("conv_bwd_weight_finish: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
+    return EFM_E_WORKSPACE;
+  }
+  const float* slabs = (const float*)workspace;
+  const float* bpart = slabs + pl.slab_floats + pl.lvl2_floats;
   const long n4w = (long)d->n_pad16 * d->k_pad / 4, n4b = d->n_pad16 / 4;
   const int gx_w = (int)efm::cdiv(n4w, 64), gx_b = dbias ? (int)efm::cdiv(n4b, 16) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, s, (const float*)slabs, dw_packed, n4w, pl.splits,
-                     (const float*)bpart, dbias, n4b, pl.bias_chunks, accumulate, gx_w);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, (hipStream_t)stream, slabs, dw_packed, n4w, pl.splits,
+                     bpart, dbias, n4b, pl.bias_chunks, accumulate, gx_w);
   return efm::check_launch("conv_wgrad_reduce");
+}
+
+int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && dy && dw_packed, "conv_bwd_weight: null argument");
+  const int rc = efm_conv_bwd_weight_slabs(d, x, dy, dbias != nullptr, workspace, workspace_bytes, stream);
+  if (rc != EFM_OK) return rc;
+  return efm_conv_bwd_weight_finish(d, dw_packed, dbias, accumulate, workspace, workspace_bytes, stream);
 }
 
 

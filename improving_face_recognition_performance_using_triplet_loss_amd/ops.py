@@ -146,6 +146,24 @@ def conv_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=Fa
     return dw, (dbias if want_bias else None)
 
 
+def conv_wgrad_workspace_bytes(d):
+    return int(_lib.load().efm_conv_wgrad_workspace_bytes(ctypes.byref(d)))
+
+
+def conv_bwd_weight_slabs(d, x, dy, ws, want_bias=True):
+    """First launch of the weight gradient (matrix-core kernel -> slabs in the caller's workspace `ws`) on the current stream."""
+    _need_dev(x, dy, ws)
+    check(_lib.load().efm_conv_bwd_weight_slabs(ctypes.byref(d), _p(x), _p(dy), int(bool(want_bias)), _p(ws), ctypes.c_size_t(ws.numel() * 4),
+                                                _stream()), "efm_conv_bwd_weight_slabs")
+
+
+def conv_bwd_weight_finish(d, ws, dw, dbias=None, accumulate=False):
+    """Second launch (fixed-order reduction of the slabs in `ws` into dw / dbias) on the current stream."""
+    _need_dev(ws, dw, dbias)
+    check(_lib.load().efm_conv_bwd_weight_finish(ctypes.byref(d), _p(dw), _p(dbias), int(bool(accumulate)), _p(ws),
+                                                 ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_conv_bwd_weight_finish")
+
+
 # ------------------------------------------------------------------------------------ elementwise
 def nchw_to_nhwc(x, out=None):
     _need_dev(x, out)

@@ -71,7 +71,12 @@ class Plan:
         self._views = {}
         self._wd_scratch = None
         self._side = None
+        self._red = None
+        self._ws2 = None
+        self._ev_pool = []
         self.two_streams = os.environ.get("EFM_TWO_STREAMS", "1") != "0"
+        # the slab reduction of layer L (pure streaming work) on a third stream, under the matrix-core kernel of layer L-1
+        self.reduce_stream = os.environ.get("EFM_REDUCE_STREAM", "1") != "0"
 
     # ------------------------------------------------------------------------------ lowering
     def _lower(self, outputs):
@@ -389,6 +394,16 @@ class Plan:
         # a second HIP stream so that each kernel's last, partially filled round of blocks is covered by the other's.
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self._side_stream() if (main is not None and self.two_streams) else None
+        red = None
+        if side is not None and self.reduce_stream and self.dtype == "f32":
+            red = self._reduce_stream()
+            need = max(ops.conv_wgrad_workspace_bytes(s.desc) for s in self.steps if s.op == "conv")
+            if self._ws2 is None or self._ws2[0].numel() * 4 < need:
+                torch.cuda.synchronize(self.device)
+                self._ws2 = [torch.empty(need // 4 + 1024, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._ws_free = [None, None]
+            self._ws_turn = 0
+            self._ev_next = 0
         if self.max_dgrad_elems and (self._wd_scratch is None or self._wd_scratch.numel() < self.max_dgrad_elems):
             self._wd_scratch = torch.empty(self.max_dgrad_elems, dtype=torch.float32, device=self.device)
         dx_input = None
@@ -405,15 +420,33 @@ class Plan:
                 wgrad = ops.convb_bwd_weight if bf else ops.conv_bwd_weight
                 wname = st.pname + "_weight"
                 acc = wname in written
-                if side is not None:
+                dwv, dbv = gv[wname], (None if st.no_bias else gv[st.pname + "_bias"])
+                if side is not None and red is not None and not bf:
+                    # three streams: slabs of this layer on `side`; their reduction on `red`, i.e. under the NEXT layer's slabs
+                    # kernel.  Two workspaces alternate; a workspace is written again only after the reduction that read it.
+                    k = self._ws_turn
+                    self._ws_turn ^= 1
                     side.wait_stream(main)
                     dy.record_stream(side)
                     with torch.cuda.stream(side):
-                        wgrad(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
-                              want_bias=not st.no_bias, accumulate=acc)
+                        if self._ws_free[k] is not None:
+                            side.wait_event(self._ws_free[k])
+                        ops.conv_bwd_weight_slabs(d, acts[src.index], dy, self._ws2[k], want_bias=not st.no_bias)
+                        ev = self._event()
+                        ev.record(side)
+                    with torch.cuda.stream(red):
+                        red.wait_event(ev)
+                        ops.conv_bwd_weight_finish(d, self._ws2[k], dwv, dbv, accumulate=acc)
+                        done = self._event()
+                        done.record(red)
+                        self._ws_free[k] = done
+                elif side is not None:
+                    side.wait_stream(main)
+                    dy.record_stream(side)
+                    with torch.cuda.stream(side):
+                        wgrad(d, acts[src.index], dy, dw=dwv, dbias=dbv, want_bias=not st.no_bias, accumulate=acc)
                 else:
-                    wgrad(d, acts[src.index], dy, dw=gv[wname], dbias=None if st.no_bias else gv[st.pname + "_bias"],
-                          want_bias=not st.no_bias, accumulate=acc)
+                    wgrad(d, acts[src.index], dy, dw=dwv, dbias=dbv, want_bias=not st.no_bias, accumulate=acc)
                 written.add(wname)
                 if st.residual is not None:
                     r = st.residual.index
@@ -436,8 +469,9 @@ class Plan:
                 if ready_cb is not None and remaining[wname] == 0:
                     ps = self.params[wname]
                     hi = ps.offset + ps.numel + (0 if st.no_bias else d.n_pad16)
-                    if side is not None:
-                        with torch.cuda.stream(side):  # the collective must order after the weight-gradient stream
+                    cb_stream = red if (red is not None and self.dtype != "bf16") else side
+                    if cb_stream is not None:
+                        with torch.cuda.stream(cb_stream):  # the collective must order after the stream that finishes the gradient
                             ready_cb(ps.offset, hi)
                     else:
                         ready_cb(ps.offset, hi)
@@ -466,6 +500,8 @@ class Plan:
                 dx_input = dy
         if side is not None:
             main.wait_stream(side)
+        if red is not None:
+            main.wait_stream(red)
         return dx_input
 
     def autotune(self, iters=5, verbose=False):
@@ -630,6 +666,19 @@ class Plan:
             # (with a default-priority stream the overlap disappeared once a process group existed: measured)
             self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
         return self._side
+
+    def _reduce_stream(self):
+        if self._red is None:
+            self._red = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
+        return self._red
+
+    def _event(self):
+        """Events from a per-plan pool (two per convolution and backward: creating them anew costs host time every step)."""
+        if self._ev_next == len(self._ev_pool):
+            self._ev_pool.append(torch.cuda.Event())
+        ev = self._ev_pool[self._ev_next]
+        self._ev_next += 1
+        return ev
 
     def routing_inputs(self):
         """{MFM / pooling node name -> its INPUT activation as an NCHW torch tensor} of the last forward(train=True);

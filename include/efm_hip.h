@@ -126,6 +126,15 @@ int efm_conv_bwd_data(const efm_conv_desc* d, const float* dy, const float* wd_p
  * fixed-order reduction. */
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed,
                         float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The two launches of efm_conv_bwd_weight separately: `_slabs` = the matrix-core kernel (partial gradients per pixel split + bias
+ * partials into the workspace), `_finish` = their fixed-order reduction into dw_packed / dbias (dbias NULL = no bias gradient; then
+ * `_slabs` must have been called with want_bias = 0 or its bias partials are simply ignored).  A caller may enqueue `_finish` on
+ * another stream (ordered after `_slabs` by an event) to run it under the next layer's matrix-core kernel; the workspace must stay
+ * untouched in between.  efm_conv_bwd_weight == _slabs; _finish on one stream. */
+int efm_conv_bwd_weight_slabs(const efm_conv_desc* d, const float* x, const float* dy, int want_bias, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int efm_conv_bwd_weight_finish(const efm_conv_desc* d, float* dw_packed, float* dbias, int accumulate, const void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16 tensor-core path (BASELINE configs[2]: "bf16 — MFMA conv path").  Same operators and the same reference call sites as
