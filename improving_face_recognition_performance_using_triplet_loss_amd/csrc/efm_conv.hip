@@ -882,7 +882,7 @@ int round_nt(int nt) {
 // tune field, but measured equal or slightly slower than 128 rows on LightCNN-9 (the small-N layers are bound by the 9x im2col
 // re-fetch of the A operand through L2 -> LDS, not by B-fragment re-use), so the default stops at 2.
 int pick_mt_bf16(long M, int nblocks) {
-  const int want = env_int("EFM_CONVB_MIN_BLOCKS", 768);
+  const int want = env_int("EFM_CONVB_MIN_BLOCKS", 256);  // swept 256..3072: 128-row tiles as soon as one block per CU remains
   if (env_int("EFM_CONVB_MT_MAX", 2) >= 4 && efm::cdiv(M, 256) * nblocks >= want) return 4;
   if (efm::cdiv(M, 128) * nblocks >= want) return 2;
   return 1;
