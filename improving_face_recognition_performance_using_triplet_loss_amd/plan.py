@@ -20,6 +20,22 @@ from . import graph, ops
 from ._lib import pad4
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, kind):
+    """ONE weight-gradient stream and ONE reduction stream per device and process, shared by every plan.  High priority: such a
+    stream keeps a hardware queue of its own even after RCCL has created its streams (with a default-priority stream the
+    wgrad / dgrad overlap disappeared once a process group existed: measured).  Shared: every new torch stream comes from a pool
+    that maps onto a few hardware queues — a third plan's private stream landed on the main stream's queue and its backward ran
+    45 % slower (the deeper-CNN leg of bench.py's `secondary`, 6.9 -> 10.0 ms, after the headline network had taken two streams)."""
+    key = (device.type, device.index, kind)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
+    return st
+
+
 class ParamSpec:
     __slots__ = ("name", "kind", "offset", "numel", "desc", "mx_shape", "step")
 
@@ -662,14 +678,12 @@ class Plan:
 
     def _side_stream(self):
         if self._side is None:
-            # a high-priority stream gets a hardware queue of its own even after RCCL has created its streams
-            # (with a default-priority stream the overlap disappeared once a process group existed: measured)
-            self._side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
+            self._side = _shared_stream(self.device, "side")
         return self._side
 
     def _reduce_stream(self):
         if self._red is None:
-            self._red = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("EFM_SIDE_PRIO", "-1")))
+            self._red = _shared_stream(self.device, "reduce")
         return self._red
 
     def _event(self):
