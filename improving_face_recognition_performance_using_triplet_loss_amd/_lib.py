@@ -62,6 +62,7 @@ SIGNATURES = {
     "efm_wino_supported": (c_int, [POINTER(ConvDesc)]),
     "efm_wino_u_elems": (c_size_t, [POINTER(ConvDesc), c_int]),
     "efm_wino_make_u": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]),
+    "efm_wino_make_u_batch": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "efm_wino_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 6),
     "efm_wino_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
     "efm_wino_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

@@ -497,9 +497,8 @@ __global__ void __launch_bounds__(256, 2) wino4_k(const WinoP p) {
 // both read the packed forward weights w[n_pad16][k_pad].  One thread per (n, k).
 // fused-epilogue forward (ways > 0): row r of channel block blk is output channel slice*cs + blk*cn + r % cnb, slice = r / cnb
 // (every slice of a channel in one block), rows past the last slice are zero.
-__global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin, int k_pad_src,
-                                                int cin_p, int n_rows, int nbr, int kpad, int ways, int cn, int kc) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_u_elem(long i, const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin,
+                                            int k_pad_src, int cin_p, int n_rows, int nbr, int kpad, int ways, int cn, int kc) {
   if (i >= (long)n_rows * kpad) return;
   const int nrow = (int)(i / kpad), k = (int)(i - (long)nrow * kpad);
   int n = nrow;
@@ -541,6 +540,35 @@ __global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, flo
     dst[(4 * a + 2) * plane] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
     dst[(4 * a + 3) * plane] = t[a][2];
   }
+}
+
+__global__ void __launch_bounds__(256) wino_u_k(const float* __restrict__ w, float* __restrict__ u, int dgrad, int cout, int cin, int k_pad_src,
+                                                int cin_p, int n_rows, int nbr, int kpad, int ways, int cn, int kc) {
+  wino_u_elem((long)blockIdx.x * 256 + threadIdx.x, w, u, dgrad, cout, cin, k_pad_src, cin_p, n_rows, nbr, kpad, ways, cn, kc);
+}
+
+// Every layer's U of a step in ONE launch (the weights do not change inside a step): a network's ~54 per-layer wino_u_k launches were
+// 8-microsecond kernels strung between the convolutions, each leaving the chip almost empty.  The job table travels by value
+// in the kernel arguments (no device allocation, no copy).
+struct UJob {
+  const float* w;
+  float* u;
+  int dgrad, cout, cin, k_pad_src, cin_p, n_rows, nbr, kpad, ways, cn, kc;
+  unsigned first_block;  // jobs own consecutive block ranges
+};
+constexpr int UJOBS_MAX = 56;  // 56 * 64 B = 3.5 KB of kernel arguments
+struct UJobs {
+  int n;
+  UJob j[UJOBS_MAX];
+};
+
+__global__ void __launch_bounds__(256) wino_u_multi_k(const UJobs jobs) {
+  int k = 0;
+  for (int q = 1; q < jobs.n; ++q)  // block-uniform scan over <= 56 entries
+    if (blockIdx.x >= jobs.j[q].first_block) k = q;
+  const UJob& jb = jobs.j[k];
+  wino_u_elem((long)(blockIdx.x - jb.first_block) * 256 + threadIdx.x, jb.w, jb.u, jb.dgrad, jb.cout, jb.cin, jb.k_pad_src, jb.cin_p, jb.n_rows,
+              jb.nbr, jb.kpad, jb.ways, jb.cn, jb.kc);
 }
 
 // ==========================================================================================================
@@ -916,6 +944,34 @@ int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u,
   hipLaunchKernelGGL(wino_u_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_packed, u, 0, d->cout, d->cin,
                      d->k_pad, d->cin_p, pl.n_rows, pl.NTB * 16, pl.kpad, ways, pl.cn, pl.variant == 4 ? KC4 : KC);
   return efm::check_launch("wino_mfm_make_u");
+}
+
+int efm_wino_make_u_batch(int n, const efm_conv_desc* const* descs, const float* const* w_packed, float* const* u, const int* dgrad,
+                          const int* ways, void* stream) {
+  EFM_REQUIRE(n >= 0 && (n == 0 || (descs && w_packed && u && dgrad && ways)), "wino_make_u_batch: null argument");
+  int done = 0;
+  while (done < n) {
+    UJobs jobs;
+    unsigned blocks = 0;
+    jobs.n = 0;
+    for (; done < n && jobs.n < UJOBS_MAX; ++done) {
+      const efm_conv_desc* d = descs[done];
+      EFM_REQUIRE(efm_wino_supported(d) && w_packed[done] && u[done], "wino_make_u_batch: job %d: unsupported descriptor or null pointer", done);
+      const int wy = ways[done];
+      EFM_REQUIRE(wy == 0 || ((wy == 2 || wy == 3) && !dgrad[done] && d->cout % wy == 0), "wino_make_u_batch: job %d: bad ways %d", done, wy);
+      const WinoPlan pl = dgrad[done] ? plan_wino(d->cout_p, d->cin, d->tune_dgrad) : plan_wino(d->cin_p, d->cout, d->tune_fwd, wy);
+      UJob& jb = jobs.j[jobs.n++];
+      jb.w = w_packed[done]; jb.u = u[done];
+      jb.dgrad = dgrad[done] ? 1 : 0; jb.cout = d->cout; jb.cin = d->cin; jb.k_pad_src = d->k_pad; jb.cin_p = d->cin_p;
+      jb.n_rows = pl.n_rows; jb.nbr = pl.NTB * 16; jb.kpad = pl.kpad; jb.ways = wy; jb.cn = pl.cn; jb.kc = pl.variant == 4 ? KC4 : KC;
+      jb.first_block = blocks;
+      blocks += (unsigned)efm::cdiv((long)pl.n_rows * pl.kpad, 256);
+    }
+    if (blocks) hipLaunchKernelGGL(wino_u_multi_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+    const int rc = efm::check_launch("wino_make_u_batch");
+    if (rc != EFM_OK) return rc;
+  }
+  return EFM_OK;
 }
 
 int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z, unsigned char* route, int ways,

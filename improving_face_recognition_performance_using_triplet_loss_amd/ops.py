@@ -495,6 +495,24 @@ def wino_make_u(d, w, dgrad=False, out=None):
     return u
 
 
+def wino_u_numel(d, dgrad=False, ways=0):
+    lib = _lib.load()
+    return int(lib.efm_wino_mfm_u_elems(ctypes.byref(d), ways) if ways else lib.efm_wino_u_elems(ctypes.byref(d), 1 if dgrad else 0))
+
+
+def wino_make_u_batch(jobs):
+    """jobs: list of (desc, packed weights, u buffer, dgrad flag, ways) -> every U in one launch (efm_wino_make_u_batch)."""
+    n = len(jobs)
+    if not n:
+        return
+    descs = (ctypes.POINTER(_lib.ConvDesc) * n)(*[ctypes.pointer(j[0]) for j in jobs])
+    ws = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+    us = (ctypes.c_void_p * n)(*[j[2].data_ptr() for j in jobs])
+    dg = (ctypes.c_int * n)(*[1 if j[3] else 0 for j in jobs])
+    wy = (ctypes.c_int * n)(*[int(j[4]) for j in jobs])
+    check(_lib.load().efm_wino_make_u_batch(n, descs, ws, us, dg, wy, _stream()), "efm_wino_make_u_batch")
+
+
 def wino_fwd(d, x, u, bias=None, residual=None, out=None):
     _need_dev(x, u)
     y = out if out is not None else torch.empty((d.batch, d.hout, d.wout, d.cout_p), dtype=torch.float32, device=x.device)

@@ -90,6 +90,7 @@ class Plan:
         self._red = None
         self._ws2 = None
         self._ev_pool = []
+        self._u_dgrad_ready = False
         self.two_streams = os.environ.get("EFM_TWO_STREAMS", "1") != "0"
         # the slab reduction of layer L (pure streaming work) on a third stream, under the matrix-core kernel of layer L-1
         self.reduce_stream = os.environ.get("EFM_REDUCE_STREAM", "1") != "0"
@@ -259,6 +260,29 @@ class Plan:
                 need_d = st.inputs[0].needs_grad
                 st.wb, st.wdb = ops.convb_cast_weights(st.desc, v[st.pname + "_weight"], st.wb, st.wdb, need_dgrad=need_d)
 
+    def _make_wino_u(self, v, train):
+        """Transformed weights U = G g G^T of every Winograd layer — forward and (when training) data gradient — in ONE launch at the
+        start of the step: the weights are fixed inside a step, and ~54 per-layer transforms were 8-microsecond kernels strung
+        between the convolutions (0.45 ms of the step).  Buffers are per step-object and re-used."""
+        jobs = []
+        for st in self.steps:
+            if st.op != "conv" or getattr(st, "f32", False):
+                continue
+            w = v[st.pname + "_weight"]
+            if getattr(st, "wino_fwd", False):
+                ways = st.epi["ways"] if st.epi is not None else 0
+                n = ops.wino_u_numel(st.desc, False, ways)
+                if getattr(st, "u_fwd", None) is None or st.u_fwd.numel() != n:
+                    st.u_fwd = torch.empty((n,), dtype=torch.float32, device=self.device)
+                jobs.append((st.desc, w, st.u_fwd, False, ways))
+            if train and getattr(st, "wino_dgrad", False) and st.inputs[0].needs_grad:
+                n = ops.wino_u_numel(st.desc, True, 0)
+                if getattr(st, "u_dgrad", None) is None or st.u_dgrad.numel() != n:
+                    st.u_dgrad = torch.empty((n,), dtype=torch.float32, device=self.device)
+                jobs.append((st.desc, w, st.u_dgrad, True, 0))
+        self._u_dgrad_ready = bool(train)
+        ops.wino_make_u_batch(jobs)
+
     # --------------------------------------------------------------------------- parameters
     def new_flat(self):
         return torch.zeros(self.num_flat, dtype=torch.float32, device=self.device)
@@ -334,6 +358,8 @@ class Plan:
         bf = self.dtype == "bf16"
         if bf:
             self._cast_weights(v)
+        else:
+            self._make_wino_u(v, train)
         for st in self.steps:
             if st.op == "input":
                 acts[st.index] = ops.nchw_to_nhwc_bf16(x.contiguous()) if bf else ops.nchw_to_nhwc(x.contiguous())
@@ -352,7 +378,6 @@ class Plan:
                 if st.epi is not None:
                     e = st.epi
                     if getattr(st, "wino_fwd", False):
-                        st.u_fwd = ops.wino_mfm_make_u(st.desc, w, e["ways"], out=getattr(st, "u_fwd", None))
                         acts[st.index], aux[st.index] = ops.wino_mfm_fwd(st.desc, acts[st.inputs[0].index], st.u_fwd, bias, e["ways"],
                                                                          e["order"], e["pool"])
                     else:
@@ -361,7 +386,6 @@ class Plan:
                     continue
                 res = acts[st.residual.index] if st.residual is not None else None
                 if getattr(st, "wino_fwd", False):  # Winograd F(2x2,3x3): chosen by autotune() where it is faster
-                    st.u_fwd = ops.wino_make_u(st.desc, w, out=getattr(st, "u_fwd", None))
                     acts[st.index] = ops.wino_fwd(st.desc, acts[st.inputs[0].index], st.u_fwd, bias, res)
                 else:
                     acts[st.index] = ops.conv_fwd(st.desc, acts[st.inputs[0].index], w, bias, res)
@@ -473,7 +497,8 @@ class Plan:
                     prev = gr.pop(src.index, None)
                     gr[src.index] = ops.convb_bwd_data(d, dy, st.wdb, add=prev)
                 elif getattr(st, "wino_dgrad", False) and src.needs_grad:
-                    st.u_dgrad = ops.wino_make_u(d, v[wname], dgrad=True, out=getattr(st, "u_dgrad", None))
+                    if not self._u_dgrad_ready:  # forward(train=False) followed by backward is not a sequence this plan runs
+                        raise RuntimeError("backward() needs forward(train=True)")
                     prev = gr.pop(src.index, None)
                     gr[src.index] = ops.wino_bwd_data(d, dy, st.u_dgrad, add=prev)
                 elif src.needs_grad or (src.op == "input" and need_input_grad):

@@ -223,6 +223,11 @@ int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy,
                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t efm_wino_mfm_u_elems(const efm_conv_desc* d, int ways);
 int efm_wino_mfm_make_u(const efm_conv_desc* d, const float* w_packed, float* u, int ways, void* stream);
+/* n transformed-weight tensors in ONE launch (the weights of a step are fixed): job q = efm_wino_make_u(descs[q], w_packed[q], u[q],
+ * dgrad[q]) when ways[q] == 0, efm_wino_mfm_make_u(descs[q], w_packed[q], u[q], ways[q]) otherwise (then dgrad[q] must be 0).
+ * The arrays are HOST arrays of device pointers / flags; results are identical to the per-layer calls. */
+int efm_wino_make_u_batch(int n, const efm_conv_desc* const* descs, const float* const* w_packed, float* const* u, const int* dgrad,
+                          const int* ways, void* stream);
 int efm_wino_mfm_fwd(const efm_conv_desc* d, const float* x, const float* u, const float* bias, float* z,
                      unsigned char* route, int ways, int order, int pool, void* stream);
 
