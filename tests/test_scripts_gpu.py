@@ -222,3 +222,43 @@ def test_image_record_iter_device_augmentation_is_bit_identical(tmp_path):
                 assert torch.equal(bd.data[0].cpu(), bh.data[0]) and torch.equal(bd.label[0], bh.label[0])
                 n += 1
             assert n == 3
+
+
+def test_pretrained_head_step_vs_oracle():
+    """Entry point 2's step (ref: pre-trained_efm_v3.py:197-212): Wnx = Dense(128, no bias)(342-d features), anchors / positives / detached
+    negatives, TripletLoss(0.5) on the UN-normalised Wnx, ones head-gradient, SGD with rescale 1/batch_size and wd 1e-5 — the modules the
+    drop-in script composes (nn.Dense on the implicit-GEMM kernels, TripletLoss, gather_negatives, Trainer) against the NumPy oracle
+    at the script's own batch layout, three consecutive updates."""
+    from oracle import efm_oracle as O
+    from improving_face_recognition_performance_using_triplet_loss_amd import functional as F_
+    from improving_face_recognition_performance_using_triplet_loss_amd.nn import Dense, Trainer, TripletLoss
+    from tests.util import rel_err
+    B, D, E, lr, wd, margin = 64, 342, 128, 0.00024, 0.00001, 0.5
+    rng = np.random.default_rng(3)
+    w = rng.uniform(-0.1, 0.1, size=(E, D))
+    net = Dense(E, use_bias=False, in_units=D)
+    net.load_weight_mx(w)
+    trainer = Trainer(net.parameters(), "sgd", learning_rate=lr, wd=wd)
+    loss_fn = TripletLoss(margin=margin)
+    wr = w.copy()
+    for step in range(3):
+        x = rng.normal(size=(2 * B, D))
+        neg = rng.integers(0, B, size=B).astype(np.int32)
+        Wnx = net(torch.as_tensor(x, dtype=torch.float32).cuda())
+        anc, pos = Wnx[0:B], Wnx[B:2 * B]
+        ngt = F_.gather_negatives(Wnx, torch.as_tensor(neg).cuda())
+        loss = loss_fn(anc, pos, ngt)
+        loss.sum().backward()
+        # oracle
+        er = x @ wr.T
+        a, p, n = er[:B], er[B:], er[neg]
+        lr_ = O.triplet_loss(a, p, n, margin)
+        da, dp, _ = O.triplet_loss_bwd(a, p, n, lr_, np.ones(B))
+        gw = np.concatenate([da, dp]).T @ x
+        assert rel_err(loss.detach().cpu().numpy(), lr_) < 1e-4
+        before = net.weight_mx().double().cpu().numpy()
+        trainer.step(B)
+        wr = O.sgd_step(wr, gw, lr, wd, 1.0 / B)
+        after = net.weight_mx().double().cpu().numpy()
+        assert rel_err(after - before, wr - before) < 1e-3, step     # the update itself
+        assert rel_err(after, wr) < 1e-6
