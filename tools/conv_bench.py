@@ -36,9 +36,17 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--net", choices=["efm", "lightcnn9"], default="efm")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--tuned", action="store_true", help="apply the committed kernel-selection table (tuning/*.json): 'fwd' / 'dgrad' then "
+                                                         "time whatever kernel the table names for the layer, Winograd included")
     a = ap.parse_args()
     net = efm_symbol.embedding_net() if a.net == "efm" else efm_symbol.lightcnn9_embedding_net()
     plan = Plan(net, (a.batch, 3, a.image, a.image), fuse=True, dtype=a.dtype)
+    if a.tuned:
+        from improving_face_recognition_performance_using_triplet_loss_amd import tuning
+        table, src = tuning.load(a.net, a.batch, a.image, a.dtype)
+        assert table is not None, "no committed table for this configuration"
+        plan.apply_tuning(table)
+        print("# kernel selection:", src)
     bf = a.dtype == "bf16"
     want = set(a.layers.split(",")) if a.layers else None
     what = a.what.split(",")
@@ -97,6 +105,27 @@ def main():
                 else:
                     u = ops.wino_make_u(d, w, dgrad=True)
                     ms = timeit(lambda: ops.wino_bwd_data(d, dy, u, out=dx), a.iters)
+            elif k == "fwd" and a.tuned:   # the launch the plan makes for this layer's forward
+                e = st.epi
+                if e is not None and getattr(st, "wino_fwd", False):
+                    u = ops.wino_mfm_make_u(d, w, e["ways"])
+                    ms = timeit(lambda: ops.wino_mfm_fwd(d, x, u, b, e["ways"], e["order"], e["pool"]), a.iters)
+                elif e is not None:
+                    ms = timeit(lambda: ops.conv_mfm_fwd(d, x, w, b, e["ways"], e["order"], e["pool"]), a.iters)
+                elif getattr(st, "wino_fwd", False):
+                    u = ops.wino_make_u(d, w)
+                    ms = timeit(lambda: ops.wino_fwd(d, x, u, b, out=y), a.iters)
+                else:
+                    ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
+                line += " [%s]" % ops.conv_kernel_info(d, (5 if getattr(st, "wino_fwd", False) else 1) if e is not None else (4 if getattr(st, "wino_fwd", False) else 0),
+                                                       e["ways"] if e else 0, e["pool"] if e else False)[0]
+            elif k == "dgrad" and a.tuned:
+                if getattr(st, "wino_dgrad", False):
+                    u = ops.wino_make_u(d, w, dgrad=True)
+                    ms = timeit(lambda: ops.wino_bwd_data(d, dy, u, out=dx), a.iters)
+                else:
+                    ms = timeit(lambda: ops.conv_bwd_data(d, dy, wd, out=dx), a.iters)
+                line += " [%s]" % ops.conv_kernel_info(d, 6 if getattr(st, "wino_dgrad", False) else 2)[0]
             elif k == "fwd":
                 ms = timeit(lambda: ops.conv_fwd(d, x, w, b, out=y), a.iters)
                 if st.epi is not None:
