@@ -190,6 +190,28 @@ __device__ __forceinline__ float quad(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// Column step of the input transform B^T d B for the forward / data-gradient kernels, ONE instruction per element.
+// Lane c of a quad holds the row-combined value t(c) of patch column c and produces output column j = c:
+//   j=0: t0 - t2,  j=1: t1 + t2,  j=2: t2 - t1,  j=3: t1 - t3.
+// Every one of them is (own value) +- (one neighbour, quad_perm [2,2,1,1]) — except that column 3 comes out NEGATED: own - nb =
+// t3 - t1.  The sign is folded into U: wino_u_k negates the planes xi = 4i + 3, and (-V)(-U) = VU bit for bit.  So the step is
+// t += r * quad_perm(t) with r = -1, +1, -1, -1, a single v_fmac_f32_dpp that reads and writes the same register (all lanes read
+// before any writes) — 16 VALU per chunk where two v_mov_b32_dpp + one v_fma per element made 48.  The s_nop covers the two wait
+// states a DPP read needs after a VALU write of the same register (inline asm is invisible to the compiler's hazard pass); the
+// four instructions of a block touch four different registers.
+__device__ __forceinline__ void col_step4(f32x4& t, float r) {
+  float a = t[0], b = t[1], c = t[2], d = t[3];
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+      : "v"(r));
+  t = f32x4{a, b, c, d};
+}
+
 // Block = 512 threads = 8 waves = 64 tiles x (16*NTB) output channels x all 16 xi.  The kernel is bound by the bytes in flight
 // between L2 and LDS (a chunk is consumed in ~2 us, a load takes ~2.6 us under load, and LDS holds two stages), so the tile is
 // as large as the 160 KB of LDS and the 256 registers per lane allow (the U chunk, 16*NB*8 floats, is shared by 64 tiles), and the
@@ -258,15 +280,8 @@ __device__ __forceinline__ void wino_body(const WinoP& p, float* smem) {
     const int vrow = (tt ^ (c << 1)) * KC + q * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // column step: j=0: c0 - c2, j=1: c1 + c2, j=2: c2 - c1, j=3: c1 - c3
-        const float a = quad<0x64>(t[i][e]);   // quad_perm [0,1,2,1]
-        const float s = quad<0xDA>(t[i][e]);   // quad_perm [2,2,1,3]
-        v[e] = a + sg * s;
-      }
-      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC) + vrow) = v;
+      col_step4(t[i], sg);  // column 3 is stored negated (see col_step4): U's planes 4i+3 carry the other minus sign
+      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC) + vrow) = t[i];
     }
   };
 
@@ -412,14 +427,8 @@ __device__ __forceinline__ void wino4_body(const WinoP& p, float* smem) {
     const int vrow = (tt ^ (c << 1)) * KC4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = quad<0x64>(t[i][e]);   // quad_perm [0,1,2,1]
-        const float s = quad<0xDA>(t[i][e]);   // quad_perm [2,2,1,3]
-        v[e] = a + sg * s;
-      }
-      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC4) + vrow) = v;
+      col_step4(t[i], sg);  // column 3 is stored negated (see col_step4): U's planes 4i+3 carry the other minus sign
+      *reinterpret_cast<f32x4*>(Vs + (4 * i + c) * (TB * KC4) + vrow) = t[i];
     }
   };
 
@@ -538,7 +547,7 @@ __device__ __forceinline__ void wino_u_elem(long i, const float* __restrict__ w,
     dst[(4 * a + 0) * plane] = t[a][0];
     dst[(4 * a + 1) * plane] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
     dst[(4 * a + 2) * plane] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-    dst[(4 * a + 3) * plane] = t[a][2];
+    dst[(4 * a + 3) * plane] = -t[a][2];  // negated: the kernels store column 3 of V negated (col_step4)
   }
 }
 
