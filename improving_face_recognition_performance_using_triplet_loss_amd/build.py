@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libefm_hip.so")
-SOURCES = ["efm_api.hip", "efm_conv.hip", "efm_winograd.hip", "efm_elementwise.hip", "efm_head.hip", "efm_predict.hip"]
+SOURCES = ["efm_api.hip", "efm_conv.hip", "efm_winograd.hip", "efm_wino_wgrad.hip", "efm_elementwise.hip", "efm_head.hip", "efm_predict.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-source extras: the SLP vectoriser packs the Winograd weight gradient's operand transforms into v_pk_*_f32, which is slower beside MFMAs
+EXTRA = {"efm_wino_wgrad.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -29,13 +31,13 @@ def _digest(paths):
     for p in sorted(paths):
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA.items()))).encode())
     return h.hexdigest()
 
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -54,7 +56,7 @@ def build(force=False, verbose=True):
         if verbose:
             print("[efm build] up to date:", LIB)
         return LIB
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         results = list(ex.map(_compile, SOURCES))
     for _, warn in results:
         if warn.strip() and verbose:

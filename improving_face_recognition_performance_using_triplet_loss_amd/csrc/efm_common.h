@@ -39,6 +39,18 @@ size_t bias_grad_ws_floats(const efm_conv_desc* d);
 // Kernel instance name + executed MFMA flops of a Winograd launch (defined in efm_winograd.hip; passes 4..6 of efm_conv_kernel_info).
 int wino_kernel_info(const efm_conv_desc* d, int pass, int ways, char* name, size_t len, double* flops);
 int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s);
+// One launch: dw (+)= sum of `splits` slabs of n4w float4, dbias (+)= sum of `chunks` partials of n4b float4 (dbias may be null);
+// fixed order (defined in efm_conv.hip, used by both weight-gradient forms).
+int wgrad_reduce(const float* slabs, float* dw, long n4w, int splits, const float* bpart, float* dbias, long n4b, int chunks, int accumulate,
+                 hipStream_t s);
+// Weight gradient in Winograd form (efm_wino_wgrad.hip) behind efm_conv_bwd_weight_*: selected by bit 12 of tune_wgrad.
+bool wino_wgrad_selected(const efm_conv_desc* d);
+size_t wino_wgrad_ws_floats(const efm_conv_desc* d);
+int wino_wgrad_slabs(const efm_conv_desc* d, const float* x, const float* dy, int want_bias, void* workspace, size_t workspace_bytes,
+                     hipStream_t s);
+int wino_wgrad_finish(const efm_conv_desc* d, float* dw_packed, float* dbias, int accumulate, const void* workspace, size_t workspace_bytes,
+                      hipStream_t s);
+int wino_wgrad_info(const efm_conv_desc* d, char* name, size_t len, double* flops);
 
 // Raw-buffer offsets are 32 bits and the kernels use byte offset 2^31 (EFM_OOB) as the "always out of range" address that the
 // buffer range check turns into zeros (padding taps, tail rows): every activation tensor a convolution kernel addresses must

@@ -1297,6 +1297,14 @@ WgradBPlan plan_wgradb(const efm_conv_desc* d) {
 
 namespace efm {
 
+int wgrad_reduce(const float* slabs, float* dw, long n4w, int splits, const float* bpart, float* dbias, long n4b, int chunks, int accumulate,
+                 hipStream_t s) {
+  const int gx_w = (int)efm::cdiv(n4w, 64), gx_b = dbias ? (int)efm::cdiv(n4b, 16) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, s, slabs, dw, n4w, splits, bpart, dbias, n4b, chunks, accumulate,
+                     gx_w);
+  return efm::check_launch("conv_wgrad_reduce");
+}
+
 int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s) {
   const unsigned gx = (unsigned)efm::cdiv(n4, 64);
   if (count > 32) {
@@ -1362,7 +1370,10 @@ int efm_conv_desc_init(efm_conv_desc* d, int batch, int hin, int win, int cin, i
 
 size_t efm_conv_weight_elems(const efm_conv_desc* d) { return (size_t)d->n_pad16 * d->k_pad; }
 size_t efm_conv_dgrad_weight_elems(const efm_conv_desc* d) { return (size_t)d->dn_pad16 * d->dk_pad; }
-size_t efm_conv_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wgrad(d).ws_floats * sizeof(float); }
+size_t efm_conv_wgrad_workspace_bytes(const efm_conv_desc* d) {
+  if (efm::wino_wgrad_selected(d)) return efm::wino_wgrad_ws_floats(d) * sizeof(float);
+  return plan_wgrad(d).ws_floats * sizeof(float);
+}
 
 int efm_conv_pack_weights(const efm_conv_desc* d, const float* w_oihw, float* w_packed, void* stream) {
   EFM_REQUIRE(d && w_oihw && w_packed, "conv_pack_weights: null argument");
@@ -1496,6 +1507,7 @@ int efm_conv_bwd_weight_slabs(const efm_conv_desc* d, const float* x, const floa
                               size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && x && dy, "conv_bwd_weight: null argument");
   EFM_REQUIRE_RANGE(d, 4, "conv_bwd_weight");
+  if (efm::wino_wgrad_selected(d)) return efm::wino_wgrad_slabs(d, x, dy, want_bias, workspace, workspace_bytes, (hipStream_t)stream);
   const WgradPlan pl = plan_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("conv_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
@@ -1527,6 +1539,7 @@ int efm_conv_bwd_weight_slabs(const efm_conv_desc* d, const float* x, const floa
 int efm_conv_bwd_weight_finish(const efm_conv_desc* d, float* dw_packed, float* dbias, int accumulate, const void* workspace,
                                size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && dw_packed, "conv_bwd_weight_finish: null argument");
+  if (efm::wino_wgrad_selected(d)) return efm::wino_wgrad_finish(d, dw_packed, dbias, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
   const WgradPlan pl = plan_wgrad(d);
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("conv_bwd_weight_finish: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
@@ -1534,11 +1547,8 @@ int efm_conv_bwd_weight_finish(const efm_conv_desc* d, float* dw_packed, float* 
   }
   const float* slabs = (const float*)workspace;
   const float* bpart = slabs + pl.slab_floats + pl.lvl2_floats;
-  const long n4w = (long)d->n_pad16 * d->k_pad / 4, n4b = d->n_pad16 / 4;
-  const int gx_w = (int)efm::cdiv(n4w, 64), gx_b = dbias ? (int)efm::cdiv(n4b, 16) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, (hipStream_t)stream, slabs, dw_packed, n4w, pl.splits,
-                     bpart, dbias, n4b, pl.bias_chunks, accumulate, gx_w);
-  return efm::check_launch("conv_wgrad_reduce");
+  return efm::wgrad_reduce(slabs, dw_packed, (long)d->n_pad16 * d->k_pad / 4, pl.splits, bpart, dbias, d->n_pad16 / 4, pl.bias_chunks, accumulate,
+                           (hipStream_t)stream);
 }
 
 int efm_conv_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
@@ -1577,6 +1587,8 @@ int efm_conv_kernel_info(const efm_conv_desc* d, int pass, int ways, int pool, c
     const long bm = 64 * et.MT;
     fl = 2.0 * (double)(efm::cdiv(rows, bm) * bm) * (double)(et.nsplit * et.NT * 16) * (double)d->k_pad;
     snprintf(buf, sizeof(buf), "conv_fwd_k<float, %d, %d, true, 1>", et.MT, et.NT);
+  } else if (efm::wino_wgrad_selected(d)) {
+    efm::wino_wgrad_info(d, buf, sizeof(buf), &fl);
   } else {
     const WgradPlan pl = plan_wgrad(d);
     fl = 2.0 * (double)((long)pl.splits * pl.m_per_split) * (double)(pl.nblocks * pl.NTW * 16) * (double)d->k_pad;

@@ -580,238 +580,7 @@ __global__ void __launch_bounds__(256) wino_u_multi_k(const UJobs jobs) {
               jb.nbr, jb.kpad, jb.ways, jb.cn, jb.kc);
 }
 
-// ==========================================================================================================
-// Weight gradient in Winograd form:  dw = G^T [ sum_tiles (A dy A^T) .* (B^T d B) ] G
-//   dU_xi[co][ci] = sum_t P_xi[t][co] * V_xi[t][ci]   (16 GEMMs contracting over the TILES; 2.25x fewer multiplies than the direct
-//   pixel contraction), then the 4x4 -> 3x3 transform G^T . G in the epilogue, so a block's result is a slab in the ordinary packed
-//   layout [n][tap*cin_p + ci] and the fixed-order slab reduction of the direct kernel finishes the job.
-// Block = 256 threads = 4 waves = (48 output channels) x (64 input channels) x 16 xi over one split of the tiles; wave i owns
-// xi = 4i..4i+3.  Per chunk of 4 tiles both operands are transformed on the fly: V as in the forward kernel (thread = tile, channel
-// quad, patch column; DPP quad for the column step), P = A dy A^T by 192 threads (tile, channel quad, row i); LDS stage
-// [xi][tile][P 48 | V 64] = 31 KB, two stages, two blocks per CU.
-constexpr int WG_COB = 48, WG_CIB = 64, WG_KT = 4;
-constexpr int WG_RSZ = WG_COB + WG_CIB + 8;   // floats per (xi, tile) row: 120 % 32 = 24 -> the 4 tile rows of a fragment read tile the banks exactly twice
-constexpr int WG_PS = WG_KT * WG_RSZ + 8;     // floats per xi plane: 488 % 32 = 8 -> the 4 planes a DPP quad writes hit different banks
-constexpr int WG_STAGE = 16 * WG_PS;
-constexpr int WG_ES = WG_CIB + 4;
-
-struct WinoWP {
-  const float* x;
-  const float* dy;
-  float* ws;  // slabs [split][n_pad16][k_pad]
-  int batch, h, w, cin_p, cout_p;
-  int th, tw, tiles;
-  int n_pad16, k_pad;
-  int cob, cib, splits, tps;  // channel blocks, tile splits, tiles per split (multiple of 4)
-  unsigned x_bytes, y_bytes;
-  int dbg;
-};
-
-__device__ __forceinline__ int fdivw(int m, int d, float inv) {
-  int q = (int)((float)m * inv);
-  const int r = m - q * d;
-  q += (r >= d) ? 1 : 0;
-  q -= (r < 0) ? 1 : 0;
-  return q;
-}
-
-__global__ void __launch_bounds__(256, 2) wino_wgrad_k(const WinoWP p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * WG_STAGE];
-  constexpr int COT = WG_COB / 16, CIT = WG_CIB / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
-  const int fi = lane & 15, fq = lane >> 4;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int base = p.cob * p.cib;
-  const int split = lid / base, rblk = lid - split * base;
-  const int cb = rblk / p.cib, ib = rblk - cb * p.cib;
-  const int co0 = cb * WG_COB, ci0 = ib * WG_CIB;
-  const int tbeg = split * p.tps, tend = min(p.tiles, tbeg + p.tps);
-  const int chunks = (tend - tbeg + WG_KT - 1) / WG_KT;
-  const int per = p.th * p.tw;
-  const float inv_per = 1.0f / (float)per, inv_tw = 1.0f / (float)p.tw;
-
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.y_bytes, 0x00020000);
-
-  // V side: thread = (tile tv = wave, channel quad qv, patch column c)
-  const int qv = (tid >> 2) & 15, c = tid & 3;
-  const bool vok = ci0 + qv * 4 < p.cin_p;
-  // P side (threads 0..191): (tile tp, channel quad qo, row i)
-  const int tp = tid / 48, prem = tid - tp * 48, qo = prem >> 2, pi = prem & 3;
-  const bool pact = tid < 192;
-  const bool pok = pact && co0 + qo * 4 < p.cout_p;
-
-  u32x4 xreg[4], yreg[4];
-  auto load = [&](int ch) {
-    {
-      const int tile = tbeg + ch * WG_KT + wi;
-      const int b = fdivw(tile, per, inv_per), r = tile - b * per;
-      const int ty = fdivw(r, p.tw, inv_tw), tx = r - ty * p.tw;
-      const int ix = 2 * tx - 1 + c;
-      const bool tok = vok && tile < tend && (unsigned)ix < (unsigned)p.w;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int iy = 2 * ty - 1 + rr;
-        const bool ok = tok && (unsigned)iy < (unsigned)p.h;
-        xreg[rr] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((((b * p.h + iy) * p.w + ix) * p.cin_p + ci0 + qv * 4) * 4) : EFM_OOB, 0, 0);
-      }
-    }
-    if (pact) {
-      const int tile = tbeg + ch * WG_KT + tp;
-      const int b = fdivw(tile, per, inv_per), r = tile - b * per;
-      const int ty = fdivw(r, p.tw, inv_tw), tx = r - ty * p.tw;
-      const bool tok = pok && tile < tend;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int oy = 2 * ty + a, ox = 2 * tx + bb;
-          const bool ok = tok && oy < p.h && ox < p.w;
-          yreg[a * 2 + bb] = __builtin_amdgcn_raw_buffer_load_b128(yr, ok ? (unsigned)((((b * p.h + oy) * p.w + ox) * p.cout_p + co0 + qo * 4) * 4) : EFM_OOB, 0, 0);
-        }
-    }
-  };
-  auto transform = [&](int buf) {
-    float* St = smem + buf * WG_STAGE;
-    {  // V = B^T d B (as the forward kernel)
-      f32x4 d0 = __builtin_bit_cast(f32x4, xreg[0]), d1 = __builtin_bit_cast(f32x4, xreg[1]);
-      f32x4 d2 = __builtin_bit_cast(f32x4, xreg[2]), d3 = __builtin_bit_cast(f32x4, xreg[3]);
-      f32x4 t[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-      const float sg = (c == 1) ? 1.f : -1.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = quad<0x64>(t[i][e]);
-          const float s = quad<0xDA>(t[i][e]);
-          v[e] = a + sg * s;
-        }
-        *reinterpret_cast<f32x4*>(St + (4 * i + c) * WG_PS + wi * WG_RSZ + WG_COB + qv * 4) = v;
-      }
-    }
-    if (pact) {  // P = A dy A^T, A = [1 0; 1 1; 1 -1; 0 -1]: row i of A dy, then the 4 columns
-      const f32x4 y00 = __builtin_bit_cast(f32x4, yreg[0]), y01 = __builtin_bit_cast(f32x4, yreg[1]);
-      const f32x4 y10 = __builtin_bit_cast(f32x4, yreg[2]), y11 = __builtin_bit_cast(f32x4, yreg[3]);
-      f32x4 s0, s1;
-      if (pi == 0) { s0 = y00; s1 = y01; }
-      else if (pi == 1) { s0 = y00 + y10; s1 = y01 + y11; }
-      else if (pi == 2) { s0 = y00 - y10; s1 = y01 - y11; }
-      else { s0 = -y10; s1 = -y11; }
-      float* dst = St + (4 * pi) * WG_PS + tp * WG_RSZ + qo * 4;
-      *reinterpret_cast<f32x4*>(dst) = s0;
-      *reinterpret_cast<f32x4*>(dst + WG_PS) = s0 + s1;
-      *reinterpret_cast<f32x4*>(dst + 2 * WG_PS) = s0 - s1;
-      *reinterpret_cast<f32x4*>(dst + 3 * WG_PS) = -s1;
-    }
-  };
-
-  f32x4 acc[4][COT][CIT];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int m = 0; m < COT; ++m)
-#pragma unroll
-      for (int b = 0; b < CIT; ++b) acc[a][m][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto compute = [&](int buf) {
-    const float* St = smem + buf * WG_STAGE;
-#pragma unroll
-    for (int jx = 0; jx < 4; ++jx) {
-      const float* pl = St + (4 * wi + jx) * WG_PS + fq * WG_RSZ + fi;
-      float a[COT];
-#pragma unroll
-      for (int ct = 0; ct < COT; ++ct) a[ct] = pl[ct * 16];
-#pragma unroll
-      for (int it = 0; it < CIT; ++it) {
-        const float b = pl[WG_COB + it * 16];
-#pragma unroll
-        for (int ct = 0; ct < COT; ++ct) acc[jx][ct][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b, acc[jx][ct][it], 0, 0, 0);
-      }
-    }
-  };
-
-  const bool dl_ = !(p.dbg & 1), dt_ = !(p.dbg & 2), dc_ = !(p.dbg & 4);
-  if (chunks > 0) {
-    if (dl_) load(0);
-    if (dt_) transform(0);
-    if (chunks > 1 && dl_) load(1);
-  }
-  __syncthreads();
-  for (int ch = 0; ch < chunks; ++ch) {
-    if (ch + 1 < chunks && dt_) transform((ch + 1) & 1);
-    if (ch + 2 < chunks && dl_) load(ch + 2);
-    if (dc_) compute(ch & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: dw[p][q] = sum_ij G[i][p] dU[i][j] G[j][q], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  Over j in registers, over i
-  // through LDS, one filter column q per pass; rows = co, 64 contiguous ci per row.
-  float* Es = smem;  // [i][co 48][WG_ES]
-  float* slab = p.ws + (long)split * p.n_pad16 * p.k_pad;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-#pragma unroll
-    for (int ct = 0; ct < COT; ++ct)
-#pragma unroll
-      for (int it = 0; it < CIT; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float u0 = acc[0][ct][it][r], u1 = acc[1][ct][it][r], u2 = acc[2][ct][it][r], u3 = acc[3][ct][it][r];
-          const float e = (q == 0) ? (u0 + 0.5f * (u1 + u2)) : (q == 1) ? (0.5f * (u1 - u2)) : (0.5f * (u1 + u2) + u3);
-          Es[(wi * WG_COB + ct * 16 + 4 * fq + r) * WG_ES + it * 16 + fi] = e;
-        }
-    __syncthreads();
-    for (int itx = tid; itx < WG_COB * (WG_CIB / 4); itx += 256) {
-      const int cq = itx & 15, co = itx >> 4;
-      const int n = co0 + co, ci = ci0 + cq * 4;
-      if (n >= p.n_pad16 || ci >= p.cin_p) continue;
-      const f32x4 e0 = *reinterpret_cast<const f32x4*>(Es + (0 * WG_COB + co) * WG_ES + cq * 4);
-      const f32x4 e1 = *reinterpret_cast<const f32x4*>(Es + (1 * WG_COB + co) * WG_ES + cq * 4);
-      const f32x4 e2 = *reinterpret_cast<const f32x4*>(Es + (2 * WG_COB + co) * WG_ES + cq * 4);
-      const f32x4 e3 = *reinterpret_cast<const f32x4*>(Es + (3 * WG_COB + co) * WG_ES + cq * 4);
-      float* row = slab + (long)n * p.k_pad + ci;
-      *reinterpret_cast<f32x4*>(row + (0 * 3 + q) * p.cin_p) = e0 + 0.5f * (e1 + e2);
-      *reinterpret_cast<f32x4*>(row + (1 * 3 + q) * p.cin_p) = 0.5f * (e1 - e2);
-      *reinterpret_cast<f32x4*>(row + (2 * 3 + q) * p.cin_p) = 0.5f * (e1 + e2) + e3;
-    }
-    __syncthreads();
-  }
-  // the K padding of the packed layout (k in [9*cin_p, k_pad)) is written as zeros by the first input-channel block
-  if (ib == 0) {
-    const int kz = p.k_pad - 9 * p.cin_p;
-    for (int itx = tid; itx < WG_COB * kz; itx += 256) {
-      const int co = itx / kz, k = itx - co * kz;
-      if (co0 + co < p.n_pad16) slab[(long)(co0 + co) * p.k_pad + 9 * p.cin_p + k] = 0.f;
-    }
-  }
-}
-
-struct WinoWPlan {
-  int cob, cib, splits, tps;
-  size_t slab_floats, lvl2_floats, ws_floats;
-};
-
-WinoWPlan plan_wino_wgrad(const efm_conv_desc* d) {
-  WinoWPlan pl;
-  const int tiles = d->batch * ((d->hin + 1) / 2) * ((d->win + 1) / 2);
-  pl.cob = (d->n_pad16 + WG_COB - 1) / WG_COB;
-  pl.cib = (d->cin_p + WG_CIB - 1) / WG_CIB;
-  const int base = pl.cob * pl.cib;
-  static const int target = [] { const char* e = getenv("EFM_WINO_WGRAD_BLOCKS"); return e ? atoi(e) : 2048; }();
-  int splits = std::max(1, (target + base - 1) / base);
-  splits = std::min(splits, std::max(1, tiles / 128));  // at least 32 chunks per block
-  int tps = (tiles + splits - 1) / splits;
-  tps = (tps + WG_KT - 1) / WG_KT * WG_KT;
-  pl.tps = tps;
-  pl.splits = (tiles + tps - 1) / tps;
-  pl.slab_floats = (size_t)pl.splits * d->n_pad16 * d->k_pad;
-  pl.lvl2_floats = (pl.splits > 32) ? (size_t)((pl.splits + 31) / 32) * d->n_pad16 * d->k_pad : 0;
-  pl.ws_floats = pl.slab_floats + pl.lvl2_floats + efm::bias_grad_ws_floats(d);
-  return pl;
-}
+// (the weight gradient in Winograd form lives in efm_wino_wgrad.hip)
 
 struct WinoPlan {
   int NTB, nblocks, n_rows, kpad, variant;
@@ -1004,37 +773,6 @@ int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dg
   EFM_REQUIRE(efm_wino_supported(d) && dy && u_dgrad && dx, "wino_bwd_data: unsupported descriptor or null argument");
   EFM_REQUIRE_RANGE(d, 4, "wino_bwd_data");
   return run_wino(dy, u_dgrad, nullptr, add, dx, d->batch, d->hout, d->wout, d->cout_p, d->cin, d->cin_p, d->tune_dgrad, (hipStream_t)stream);
-}
-
-size_t efm_wino_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wino_wgrad(d).ws_floats * sizeof(float); }
-
-int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias, int accumulate,
-                        void* workspace, size_t workspace_bytes, void* stream) {
-  EFM_REQUIRE(efm_wino_supported(d) && x && dy && dw_packed, "wino_bwd_weight: unsupported descriptor or null argument");
-  EFM_REQUIRE_RANGE(d, 4, "wino_bwd_weight");
-  const WinoWPlan pl = plan_wino_wgrad(d);
-  if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
-    efm::set_error("wino_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
-    return EFM_E_WORKSPACE;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  WinoWP p;
-  p.x = x; p.dy = dy; p.ws = (float*)workspace;
-  p.batch = d->batch; p.h = d->hin; p.w = d->win; p.cin_p = d->cin_p; p.cout_p = d->cout_p;
-  p.th = (d->hin + 1) / 2; p.tw = (d->win + 1) / 2; p.tiles = d->batch * p.th * p.tw;
-  p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad;
-  p.cob = pl.cob; p.cib = pl.cib; p.splits = pl.splits; p.tps = pl.tps;
-  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * 4);
-  p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * d->cout_p * 4);
-  { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
-  hipLaunchKernelGGL(wino_wgrad_k, dim3((unsigned)(pl.cob * pl.cib * pl.splits)), dim3(256), 0, s, p);
-  int rc = efm::check_launch("wino_wgrad");
-  if (rc != EFM_OK) return rc;
-  float* slabs = (float*)workspace;
-  float* lvl2 = slabs + pl.slab_floats;
-  rc = efm::reduce_slabs(slabs, lvl2, dw_packed, (long)d->n_pad16 * d->k_pad / 4, pl.splits, accumulate, s);
-  if (rc != EFM_OK || !dbias) return rc;
-  return efm::bias_grad(d, dy, dbias, accumulate, lvl2 + pl.lvl2_floats, s);
 }
 
 }  // extern "C"

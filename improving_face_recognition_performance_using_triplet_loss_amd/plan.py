@@ -548,7 +548,7 @@ class Plan:
     def autotune(self, iters=5, verbose=False):
         """Time the tiling candidates (64/128-pixel tiles x 1..3 channel blocks) of every plain convolution forward and
         data gradient at this plan's shapes and store the winners in the descriptors (results are bit-identical for every
-        choice).  For the 3x3 / pad 1 layers the Winograd F(2x2,3x3) kernels (plain forward and data gradient) are timed
+        choice).  For the 3x3 / pad 1 layers the Winograd F(2x2,3x3) kernels (forward, data gradient, weight gradient) are timed
         against the winner and taken where at least 3 % faster — those layers then differ from the direct kernels by fp32
         rounding (~1e-6), not bitwise; EFM_WINO=0 keeps the direct kernels everywhere.  ~1 s at B = 256; idempotent."""
         if self.device.type != "cuda":
@@ -660,6 +660,10 @@ class Plan:
             dwt = torch.empty((d.n_pad16, d.k_pad), device=self.device)
             dbt = torch.empty((d.n_pad16,), device=self.device)
             cw = [0] + [kpw | ((blocks // 64) << 4) for kpw in (1, 2) for blocks in (768, 1024, 1536, 2560, 3840)]
+            if wino and ops.wino_supported(d) and os.environ.get("EFM_WINO_WGRAD", "1") != "0":
+                # bit 12: the Winograd form (transforms on the way from LDS to the matrix cores); bits 9:4 = blocks / 64
+                # bits 3:0 = 1 + channel-tile shape of the block (0: the one that pads this layer least)
+                cw += [0x1000 | (4 << 4), 0x1000 | (8 << 4)] + [0x1000 | (4 << 4) | sh for sh in range(1, 10)]
             chosen[st.pname + ":wgrad"] = best(lambda: ops.conv_bwd_weight(d, x, dy, dw=dwt, dbias=dbt), d, "tune_wgrad", cw)[0]
             seen[key] = (d.tune_fwd, d.tune_dgrad, st.wino_fwd, st.wino_dgrad, d.tune_wgrad)
         if verbose:
