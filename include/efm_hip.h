@@ -81,7 +81,10 @@ typedef struct efm_conv_desc {
   int32_t tune_fwd, tune_dgrad;
   /* Same for efm_conv_bwd_weight (and its workspace size, which depends on it): 0 = heuristic, else KPW | (blocks64 << 4) with
    * KPW in {1,2} (64 or 128 weight columns per block) and blocks64 = target number of thread blocks / 64 (0 = default 2560).
-   * Every choice is deterministic; different choices differ by fp32 summation order. */
+   * Every choice is deterministic; different choices differ by fp32 summation order.
+   * Bit 12 (0x1000), 3x3 / pad 1 / stride 1 geometries only: the Winograd form (efm_wino_bwd_weight's kernel) behind the same entry
+   * points — 2.25x fewer multiplies, fp32 rounding differs from the direct kernel by ~1e-6; bits 3:0 = 1 + block shape (output x input
+   * channel tiles of 16, 0 = the shape that pads the layer least), bits 9:4 = blocks to aim for / 64 (0 = one per CU). */
   int32_t tune_wgrad;
 } efm_conv_desc;
 
@@ -217,7 +220,8 @@ int efm_wino_bwd_data(const efm_conv_desc* d, const float* dy, const float* u_dg
 /* Winograd forward with the fused bias -> MFM (-> 2x2 max pooling) epilogue: same z / route outputs and tie rules as
  * efm_conv_mfm_fwd (so efm_mfm_pool_bwd is its backward), U made by efm_wino_mfm_make_u (rows grouped so that every slice of a
  * channel meets in one block). */
-/* Weight gradient in Winograd form (same outputs, workspace protocol and determinism as efm_conv_bwd_weight). */
+/* Weight gradient in Winograd form (same outputs, workspace protocol and determinism as efm_conv_bwd_weight; also reachable through
+ * efm_conv_bwd_weight{,_slabs,_finish} with bit 12 of tune_wgrad, which is how the training plan uses it). */
 size_t efm_wino_wgrad_workspace_bytes(const efm_conv_desc* d);
 int efm_wino_bwd_weight(const efm_conv_desc* d, const float* x, const float* dy, float* dw_packed, float* dbias,
                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
