@@ -31,14 +31,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Shared by the direct and the Winograd weight-gradient paths (defined in efm_conv.hip).
-// reduce_slabs: out[i] (+)= sum over `count` slabs of n4 float4 each, fixed order (two levels above 32 slabs; tmp holds ceil(count/32) slabs).
-int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s);
-// bias_grad: dbias[n_pad16] (+)= column sums of dy (M x cout_p); ws holds bias_grad_ws_floats(d) floats.
-size_t bias_grad_ws_floats(const efm_conv_desc* d);
 // Kernel instance name + executed MFMA flops of a Winograd launch (defined in efm_winograd.hip; passes 4..6 of efm_conv_kernel_info).
 int wino_kernel_info(const efm_conv_desc* d, int pass, int ways, char* name, size_t len, double* flops);
-int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s);
 // One launch: dw (+)= sum of `splits` slabs of n4w float4, dbias (+)= sum of `chunks` partials of n4b float4 (dbias may be null);
 // fixed order (defined in efm_conv.hip, used by both weight-gradient forms).
 int wgrad_reduce(const float* slabs, float* dw, long n4w, int splits, const float* bpart, float* dbias, long n4b, int chunks, int accumulate,

@@ -664,48 +664,12 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradP& p, float* smem) {
   }
 }
 
-// Bias gradient: the blocks past the matrix-core grid each column-sum BIAS_ROWS rows of dy (pure streaming work that
-// fills the tail of the launch; dy is being pulled through L2 by the MFMA blocks anyway).  Partials are reduced in a
-// fixed order by slab_reduce_k: no atomics.
-constexpr int BIAS_ROWS = 1024;
-__device__ __forceinline__ void bias_colsum_body(const WgradP& p, float* smem, int chunk) {
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int m_begin = chunk * BIAS_ROWS, m_end = min(p.M, m_begin + BIAS_ROWS);
-  const int ng = p.cout_p >> 2, ng16 = p.n_pad16 >> 2;
-  for (int g0 = 0; g0 < ng16; g0 += 64) {
-    const int g = g0 + cx;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    if (g < ng) {
-      const float* base = p.dy + g * 4;
-      int m = m_begin + ry;
-      for (; m + 12 < m_end; m += 16) {
-        s0 += *reinterpret_cast<const f32x4*>(base + (long)m * p.cout_p);
-        s1 += *reinterpret_cast<const f32x4*>(base + (long)(m + 4) * p.cout_p);
-        s2 += *reinterpret_cast<const f32x4*>(base + (long)(m + 8) * p.cout_p);
-        s3 += *reinterpret_cast<const f32x4*>(base + (long)(m + 12) * p.cout_p);
-      }
-      for (; m < m_end; m += 4) s0 += *reinterpret_cast<const f32x4*>(base + (long)m * p.cout_p);
-    }
-    *reinterpret_cast<f32x4*>(smem + (ry * 64 + cx) * 4) = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (ry == 0 && g < ng16) {
-      f32x4 t = *reinterpret_cast<f32x4*>(smem + cx * 4);
-      t += *reinterpret_cast<f32x4*>(smem + (64 + cx) * 4);
-      t += *reinterpret_cast<f32x4*>(smem + (128 + cx) * 4);
-      t += *reinterpret_cast<f32x4*>(smem + (192 + cx) * 4);
-      *reinterpret_cast<f32x4*>(p.bias_part + (long)chunk * p.n_pad16 + g * 4) = t;
-    }
-    __syncthreads();
-  }
-}
+constexpr int BIAS_ROWS = 1024;  // dy rows per bias partial (fp32: summed inside the k-block-0 blocks; bf16: column-sum blocks)
 
 template <int KPW, int NTW>
 __global__ void __launch_bounds__(256, 3) conv_wgrad_k(const WgradP p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 16 * (64 * KPW + 16 * NTW)];
-  if ((int)blockIdx.x >= p.mma_blocks)
-    bias_colsum_body(p, smem, (int)blockIdx.x - p.mma_blocks);
-  else
-    conv_wgrad_body<KPW, NTW>(p, smem);
+  conv_wgrad_body<KPW, NTW>(p, smem);
 }
 
 // out[g][i] = sum_{s in group g} ws[s*stride + i] (+ out[i] when accumulating), fixed order (deterministic).
@@ -1303,38 +1267,6 @@ int wgrad_reduce(const float* slabs, float* dw, long n4w, int splits, const floa
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, s, slabs, dw, n4w, splits, bpart, dbias, n4b, chunks, accumulate,
                      gx_w);
   return efm::check_launch("conv_wgrad_reduce");
-}
-
-int reduce_slabs(const float* in, float* tmp, float* out, long n4, int count, int accumulate, hipStream_t s) {
-  const unsigned gx = (unsigned)efm::cdiv(n4, 64);
-  if (count > 32) {
-    const int groups = (count + 31) / 32;
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, in, tmp, n4, n4, count, 32, n4, 0);
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)tmp, out, n4, n4, groups, groups, n4, accumulate);
-  } else {
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, in, out, n4, n4, count, count, n4, accumulate);
-  }
-  return efm::check_launch("slab_reduce");
-}
-
-size_t bias_grad_ws_floats(const efm_conv_desc* d) {
-  const int chunks = (d->batch * d->hout * d->wout + BIAS_ROWS - 1) / BIAS_ROWS;
-  return (size_t)(chunks + (chunks + 31) / 32) * d->n_pad16;
-}
-
-int bias_grad(const efm_conv_desc* d, const float* dy, float* dbias, int accumulate, float* ws, hipStream_t s) {
-  WgradP p;
-  memset(&p, 0, sizeof(p));
-  p.dy = dy;
-  p.M = d->batch * d->hout * d->wout;
-  p.cout_p = d->cout_p; p.n_pad16 = d->n_pad16;
-  const int chunks = (p.M + BIAS_ROWS - 1) / BIAS_ROWS;
-  p.bias_part = ws;
-  p.mma_blocks = 0;  // every block of the launch is a column-sum block
-  hipLaunchKernelGGL((conv_wgrad_k<1, 3>), dim3((unsigned)chunks), dim3(256), 0, s, p);
-  int rc = efm::check_launch("bias_grad");
-  if (rc != EFM_OK) return rc;
-  return reduce_slabs(ws, ws + (size_t)chunks * d->n_pad16, dbias, d->n_pad16 / 4, chunks, accumulate, s);
 }
 
 }  // namespace efm
