@@ -31,6 +31,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Unsigned 32-bit division by a launch constant in 5 VALU instructions (round-up multiplier, Granlund & Montgomery; exact for every
+// 32-bit dividend): the element-wise kernels turn a flat thread index into (pixel, channel) / (image, row, column) with it — a plain
+// `/` on a 64-bit index cost ~200 instructions per division there, more than the loads and stores of the kernel.
+struct FastDiv {
+  unsigned d, m, s;
+};
+inline FastDiv fastdiv(unsigned d) {
+  FastDiv f{d, 0u, 0u};
+  if (d <= 1) return f;  // div() passes the dividend through
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned div(unsigned x, const FastDiv& f) {
+  const unsigned t = __umulhi(f.m, x);
+  const unsigned q = (t + ((x - t) >> 1)) >> f.s;
+  return f.d == 1 ? x : q;
+}
+
 // Kernel instance name + executed MFMA flops of a Winograd launch (defined in efm_winograd.hip; passes 4..6 of efm_conv_kernel_info).
 int wino_kernel_info(const efm_conv_desc* d, int pass, int ways, char* name, size_t len, double* flops);
 // One launch: dw (+)= sum of `splits` slabs of n4w float4, dbias (+)= sum of `chunks` partials of n4b float4 (dbias may be null);

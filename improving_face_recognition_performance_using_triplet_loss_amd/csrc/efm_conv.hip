@@ -393,13 +393,13 @@ __global__ void __launch_bounds__(256, EFM_FWD_OCC) conv_fwd_k(const ConvP p) {
 // thread = (window or pixel, channel j); j < cs + pad channels.
 template <typename TZ, typename TY>
 __global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __restrict__ route, const TZ* __restrict__ dz,
-                                                      TY* __restrict__ dy, long items, int h, int w, int c, int ways,
-                                                      int pool, int cw, int cp, int cpo) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= items * cw) return;
-  const long it = i / cw;
-  const int j = (int)(i - it * cw);
-  const int cs = c / ways;
+                                                      TY* __restrict__ dy, unsigned total, int h, int w, int c, int cs, int ways,
+                                                      int pool, efm::FastDiv cwd, efm::FastDiv wgd, efm::FastDiv hgd, int cp, int cpo) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;  // (item, channel of a slice + pad channel): 32-bit, checked by the launcher
+  if (i >= total) return;
+  const unsigned itu = efm::div(i, cwd);
+  const int j = (int)(i - itu * cwd.d);
+  const long it = itu;
   if (!pool) {
     TY* d = dy + it * cp;
     if (j < cs) {
@@ -419,11 +419,12 @@ __global__ void __launch_bounds__(256) mfm_pool_bwd_k(const unsigned char* __res
     return;
   }
   // pooled: item = window of the ceil grid (partial windows at odd edges only write zeros)
-  const int hg = (h + 1) >> 1, wg = (w + 1) >> 1, hp = h >> 1, wp = w >> 1;
-  const int wq = (int)(it % wg);
-  const long t = it / wg;
-  const int hq = (int)(t % hg);
-  const long b = t / hg;
+  const int hp = h >> 1, wp = w >> 1;
+  const unsigned tu = efm::div(itu, wgd);
+  const int wq = (int)(itu - tu * wgd.d);
+  const unsigned bu = efm::div(tu, hgd);
+  const int hq = (int)(tu - bu * hgd.d);
+  const long b = bu;
   const bool full = hq < hp && wq < wp;
   float gmax = 0.f, gmin = 0.f;
   int rmax = -1, rmin = -1;
@@ -1418,8 +1419,10 @@ int efm_mfm_pool_bwd(const unsigned char* route, const float* dz, float* dy, int
   const int cs = c / ways, cw = cs + (efm_pad4(c) - c);
   const long items = pool ? (long)batch * ((h + 1) / 2) * ((w + 1) / 2) : (long)batch * h * w;
   const int co = (ways == 3) ? 2 * cs : cs;
+  EFM_REQUIRE(items * cw < 0x100000000L, "mfm_pool_bwd: more than 2^32 elements");
   hipLaunchKernelGGL((mfm_pool_bwd_k<float, float>), dim3((unsigned)efm::cdiv(items * cw, 256)), dim3(256), 0, (hipStream_t)stream, route,
-                     dz, dy, items, h, w, c, ways, pool ? 1 : 0, cw, efm_pad4(c), efm_pad4(co));
+                     dz, dy, (unsigned)(items * cw), h, w, c, cs, ways, pool ? 1 : 0, efm::fastdiv(cw), efm::fastdiv((w + 1) / 2),
+                     efm::fastdiv((h + 1) / 2), efm_pad4(c), efm_pad4(co));
   return efm::check_launch("mfm_pool_bwd");
 }
 
@@ -1718,13 +1721,15 @@ int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f3
                          reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cp, pad8(co));
     return efm::check_launch("convb_mfm_pool_bwd");
   }
+  EFM_REQUIRE(items * cw < 0x100000000L, "convb_mfm_pool_bwd: more than 2^32 elements");
   dim3 grid((unsigned)efm::cdiv(items * cw, 256));
+  const efm::FastDiv cwd = efm::fastdiv(cw), wgd = efm::fastdiv((w + 1) / 2), hgd = efm::fastdiv((h + 1) / 2);
   if (dz_f32)
     hipLaunchKernelGGL((mfm_pool_bwd_k<float, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, route, (const float*)dz,
-                       reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cw, cp, efm_pad4(co));
+                       reinterpret_cast<__bf16*>(dy), (unsigned)(items * cw), h, w, c, cs, ways, pool ? 1 : 0, cwd, wgd, hgd, cp, efm_pad4(co));
   else
     hipLaunchKernelGGL((mfm_pool_bwd_k<__bf16, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, route, (const __bf16*)dz,
-                       reinterpret_cast<__bf16*>(dy), items, h, w, c, ways, pool ? 1 : 0, cw, cp, pad8(co));
+                       reinterpret_cast<__bf16*>(dy), (unsigned)(items * cw), h, w, c, cs, ways, pool ? 1 : 0, cwd, wgd, hgd, cp, pad8(co));
   return efm::check_launch("convb_mfm_pool_bwd");
 }
 

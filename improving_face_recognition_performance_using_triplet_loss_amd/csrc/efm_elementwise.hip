@@ -43,13 +43,13 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_k(const float* __restrict__ 
 // thread = (row, j) with j < cw = c/ways + (pad channels of y); consecutive threads walk j so
 // each of the `ways` slice reads and both writes are coalesced runs.
 template <int WAYS, typename T = float>
-__global__ void __launch_bounds__(256) mfm_fwd_k(const T* __restrict__ x, T* __restrict__ y, long rows,
-                                                 int c, int cp_in, int cp_out, int cw) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * cw) return;
-  const long row = i / cw;
-  const int j = (int)(i - row * cw);
-  const int cs = c / WAYS;
+__global__ void __launch_bounds__(256) mfm_fwd_k(const T* __restrict__ x, T* __restrict__ y, unsigned total,
+                                                 int cs, int cp_in, int cp_out, efm::FastDiv cwd) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;  // (row, channel of a slice + pad channel): 32-bit, checked by the launcher
+  if (i >= total) return;
+  const unsigned rowu = efm::div(i, cwd);
+  const int j = (int)(i - rowu * cwd.d);
+  const long row = rowu;
   const T* xr = x + row * cp_in;
   T* yr = y + row * cp_out;
   if (j < cs) {
@@ -71,13 +71,13 @@ __global__ void __launch_bounds__(256) mfm_fwd_k(const T* __restrict__ x, T* __r
 // ORDER_GROUP: max(max(s0,s1),s2); ORDER_RES: max(s2, max(s0,s1)).
 template <int WAYS, typename T = float>
 __global__ void __launch_bounds__(256) mfm_bwd_k(const T* __restrict__ x, const T* __restrict__ dy,
-                                                 const T* __restrict__ add, T* __restrict__ dx, long rows,
-                                                 int c, int cp_in, int cp_out, int cw, int order) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * cw) return;
-  const long row = i / cw;
-  const int j = (int)(i - row * cw);
-  const int cs = c / WAYS;
+                                                 const T* __restrict__ add, T* __restrict__ dx, unsigned total,
+                                                 int cs, int cp_in, int cp_out, efm::FastDiv cwd, int order) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned rowu = efm::div(i, cwd);
+  const int j = (int)(i - rowu * cwd.d);
+  const long row = rowu;
   const T* xr = x + row * cp_in;
   const T* gr = dy + row * cp_out;
   T* dr = dx + row * cp_in;
@@ -251,11 +251,12 @@ int efm_mfm_fwd(const float* x, float* y, int64_t rows, int c, int ways, void* s
   const int cp_in = efm_pad4(c), cp_out = efm_pad4(cout);
   const int cw = cs + (cp_out - cout);
   const long n = rows * cw;
+  EFM_REQUIRE(n < 0x100000000L, "mfm: more than 2^32 elements");
   dim3 grid((unsigned)efm::cdiv(n, 256));
   if (ways == 3)
-    hipLaunchKernelGGL(mfm_fwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, c, cp_in, cp_out, cw);
+    hipLaunchKernelGGL(mfm_fwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (unsigned)((long)rows * cw), c / 3, cp_in, cp_out, efm::fastdiv(cw));
   else
-    hipLaunchKernelGGL(mfm_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, c, cp_in, cp_out, cw);
+    hipLaunchKernelGGL(mfm_fwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, y, (unsigned)((long)rows * cw), c / 2, cp_in, cp_out, efm::fastdiv(cw));
   return efm::check_launch("mfm_fwd");
 }
 
@@ -268,13 +269,12 @@ int efm_mfm_bwd(const float* x, const float* dy, const float* add, float* dx, in
   const int cp_in = efm_pad4(c), cp_out = efm_pad4(cout);
   const int cw = cs + (cp_in - c);
   const long n = rows * cw;
+  EFM_REQUIRE(n < 0x100000000L, "mfm: more than 2^32 elements");
   dim3 grid((unsigned)efm::cdiv(n, 256));
   if (ways == 3)
-    hipLaunchKernelGGL(mfm_bwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (long)rows, c, cp_in,
-                       cp_out, cw, order);
+    hipLaunchKernelGGL(mfm_bwd_k<3>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (unsigned)((long)rows * cw), c / 3, cp_in, cp_out, efm::fastdiv(cw), order);
   else
-    hipLaunchKernelGGL(mfm_bwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (long)rows, c, cp_in,
-                       cp_out, cw, order);
+    hipLaunchKernelGGL(mfm_bwd_k<2>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, add, dx, (unsigned)((long)rows * cw), c / 2, cp_in, cp_out, efm::fastdiv(cw), order);
   return efm::check_launch("mfm_bwd");
 }
 
@@ -291,9 +291,9 @@ int efm_mfmb_fwd(const uint16_t* x, uint16_t* y, int64_t rows, int c, int ways, 
   const __bf16* xb = reinterpret_cast<const __bf16*>(x);
   __bf16* yb = reinterpret_cast<__bf16*>(y);
   if (ways == 3)
-    hipLaunchKernelGGL((mfm_fwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (long)rows, c, cp_in, cp_out, cw);
+    hipLaunchKernelGGL((mfm_fwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (unsigned)((long)rows * cw), c / 3, cp_in, cp_out, efm::fastdiv(cw));
   else
-    hipLaunchKernelGGL((mfm_fwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (long)rows, c, cp_in, cp_out, cw);
+    hipLaunchKernelGGL((mfm_fwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, yb, (unsigned)((long)rows * cw), c / 2, cp_in, cp_out, efm::fastdiv(cw));
   return efm::check_launch("mfmb_fwd");
 }
 
@@ -309,9 +309,9 @@ int efm_mfmb_bwd(const uint16_t* x, const uint16_t* dy, const uint16_t* add, uin
   const __bf16 *xb = reinterpret_cast<const __bf16*>(x), *gb = reinterpret_cast<const __bf16*>(dy), *ab = reinterpret_cast<const __bf16*>(add);
   __bf16* db = reinterpret_cast<__bf16*>(dx);
   if (ways == 3)
-    hipLaunchKernelGGL((mfm_bwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (long)rows, c, cp_in, cp_out, cw, order);
+    hipLaunchKernelGGL((mfm_bwd_k<3, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (unsigned)((long)rows * cw), c / 3, cp_in, cp_out, efm::fastdiv(cw), order);
   else
-    hipLaunchKernelGGL((mfm_bwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (long)rows, c, cp_in, cp_out, cw, order);
+    hipLaunchKernelGGL((mfm_bwd_k<2, __bf16>), grid, dim3(256), 0, (hipStream_t)stream, xb, gb, ab, db, (unsigned)((long)rows * cw), c / 2, cp_in, cp_out, efm::fastdiv(cw), order);
   return efm::check_launch("mfmb_bwd");
 }
 
