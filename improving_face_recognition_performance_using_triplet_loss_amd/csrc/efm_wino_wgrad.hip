@@ -133,6 +133,10 @@ __device__ __forceinline__ void ww_main_loop(const WWCtx& c, float* smem, f32x4 
       load_px<CIT>(xb + XROW0 + C2 * G::CHX, d0[2]); load_px<CIT>(xb + XROW1 + C2 * G::CHX, d1[2]);
 #pragma unroll
       for (int n = 0; n < CIT; ++n) {
+#ifdef EFM_WW_NOXFORM  // ablation build: operands = raw pixels, no +- combinations
+        va[n] = d0[0][n]; vb[n] = d1[1][n];
+        continue;
+#endif
         const float r0 = XADD ? d0[0][n] + d1[0][n] : d0[0][n] - d1[0][n];
         const float r1 = XADD ? d0[1][n] + d1[1][n] : d0[1][n] - d1[1][n];
         const float r2 = XADD ? d0[2][n] + d1[2][n] : d0[2][n] - d1[2][n];
@@ -156,6 +160,10 @@ __device__ __forceinline__ void ww_main_loop(const WWCtx& c, float* smem, f32x4 
       }
 #pragma unroll
       for (int m = 0; m < COT; ++m) {
+#ifdef EFM_WW_NOXFORM
+        pa[m] = s0[m]; pb[m] = s1[m];
+        continue;
+#endif
         if (PAR == 0) { pa[m] = s0[m]; pb[m] = s0[m] + s1[m]; }
         else          { pa[m] = s0[m] - s1[m]; pb[m] = s1[m]; }
       }

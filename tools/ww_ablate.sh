@@ -1,28 +1,31 @@
 #!/bin/bash
-# Ablation builds of the Winograd weight-gradient kernel (run HERE, before gpurun): tools/ab/libefm_ww_{noload,nomfma}.so = the in-tree
-# objects with efm_wino_wgrad.hip recompiled under -DEFM_WW_NOLOAD / -DEFM_WW_NOMFMA.  On the box: tools/ww_ablate.sh run [layers]
+# Ablation builds of the Winograd weight-gradient kernel (profiles/round2_wino_wgrad.md).
+#   HERE, before gpurun:  tools/ww_ablate.sh            builds tools/ab/libefm_ww_<variant>.so = the in-tree objects with
+#                                                       efm_wino_wgrad.hip recompiled under the variant's -DEFM_WW_* flags
+#   on the box:           tools/ww_ablate.sh run [layers] [shape]   times every variant with and without the LDS-DMA staging
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
 P=$R/improving_face_recognition_performance_using_triplet_loss_amd
+declare -A FLAGS=( [nobarrier]="-DEFM_WW_NOBARRIER" [noload]="-DEFM_WW_NOLOAD" [noxform]="-DEFM_WW_NOXFORM" [nomfma]="-DEFM_WW_NOMFMA"
+                   [nomfma_noload]="-DEFM_WW_NOMFMA -DEFM_WW_NOLOAD" [mfmaonly]="-DEFM_WW_NOLOAD -DEFM_WW_NOXFORM"
+                   [mfmaonly_nobarrier]="-DEFM_WW_NOLOAD -DEFM_WW_NOXFORM -DEFM_WW_NOBARRIER" )
+ORDER="nobarrier noload noxform nomfma nomfma_noload mfmaonly mfmaonly_nobarrier"
 if [ "$1" = run ]; then
-  L=${2:-conv3,conv4_res_r,conv2}
-  for V in base noload nomfma nodma; do
-    unset EFM_LIB_PATH EFM_WINO_DBG
-    case $V in
-      noload) export EFM_LIB_PATH=$R/tools/ab/libefm_ww_noload.so;;
-      nomfma) export EFM_LIB_PATH=$R/tools/ab/libefm_ww_nomfma.so;;
-      nodma) export EFM_WINO_DBG=1;;
-    esac
-    echo "== $V"
-    python $R/tools/conv_bench.py --tuned --what wwgrad --iters 10 --layers $L 2>&1 | grep "k3"
+  L=${2:-conv3}
+  S=${3:-5x3}
+  for V in base $ORDER; do
+    for D in 0 1; do
+      unset EFM_LIB_PATH
+      [ $V != base ] && export EFM_LIB_PATH=$R/tools/ab/libefm_ww_$V.so
+      echo "== $V staging $([ $D = 1 ] && echo off || echo on)"
+      EFM_WINO_DBG=$D EFM_WINO_WGRAD_SHAPE=$S python $R/tools/conv_bench.py --tuned --what wwgrad --iters 10 --layers $L 2>&1 | grep "k3"
+    done
   done
   exit 0
 fi
 mkdir -p $R/tools/ab /tmp/ww_ab
-for V in NOLOAD NOMFMA; do
-  v=$(echo $V | tr A-Z a-z)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -DEFM_WW_$V -c $P/csrc/efm_wino_wgrad.hip -o /tmp/ww_ab/ww_$v.o
-  OBJS=$(ls $P/csrc/_obj/*.o | grep -v efm_wino_wgrad.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ab/libefm_ww_$v.so $OBJS /tmp/ww_ab/ww_$v.o
+for V in $ORDER; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize ${FLAGS[$V]} -c $P/csrc/efm_wino_wgrad.hip -o /tmp/ww_ab/ww_$V.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ab/libefm_ww_$V.so $(ls $P/csrc/_obj/*.o | grep -v efm_wino_wgrad.o) /tmp/ww_ab/ww_$V.o
 done
 ls -la $R/tools/ab/
