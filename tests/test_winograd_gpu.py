@@ -213,3 +213,27 @@ def test_wino_wgrad_behind_conv_bwd_weight(shape):
         assert torch.equal(dwm, dw)                       # pad rows / columns are exactly zero
         d.tune_wgrad = 0
         assert ops.conv_kernel_info(d, ops.PASS_WGRAD)[0].startswith("conv_wgrad_k<")
+
+
+def test_wino_wgrad_random_geometries():
+    """Seeded sweep of odd geometries (1..3 images, 1..23 pixels per side, 1..150 channels) through every block shape: the Winograd
+    weight gradient (+ bias gradient) against the direct kernel on the same device tensors, pads exactly zero."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    rng = np.random.default_rng(20261005)
+    for trial in range(24):
+        b, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        cin, cout = int(rng.integers(1, 151)), int(rng.integers(1, 151))
+        d = ops.conv_desc(b, h, w, cin, cout, 3, 3, 1, 1)
+        xd = torch.zeros((b, h, w, d.cin_p), device="cuda")
+        xd[..., :cin] = torch.rand((b, h, w, cin), device="cuda") - 0.5
+        dyd = torch.zeros((b, h, w, d.cout_p), device="cuda")
+        dyd[..., :cout] = torch.rand((b, h, w, cout), device="cuda") - 0.5
+        dwd, dbd = ops.conv_bwd_weight(d, xd, dyd)
+        scale = float(dwd.abs().max()) + 1e-30
+        d.tune_wgrad = 0x1000 | (4 << 4) | (trial % (len(WGRAD_SHAPES) + 1))
+        dw, db = ops.conv_bwd_weight(d, xd, dyd)
+        assert float((dw - dwd).abs().max()) / scale < 1e-5, (trial, b, h, w, cin, cout)
+        assert float((db - dbd).abs().max()) / (float(dbd.abs().max()) + 1e-30) < 1e-5, (trial, b, h, w, cin, cout)
+        dwm = dw.clone()
+        ops.conv_pack_weights_into(d, ops.conv_unpack_weights(d, dw), dwm)
+        assert torch.equal(dwm, dw), (trial, b, h, w, cin, cout)
