@@ -939,8 +939,9 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   const int ktiles = d->k_pad / 16, ntiles = d->n_pad16 / 16;
   // 8 k-tiles per block whenever that saves a k-block: dy is re-read once per k-block, and the narrow-K layers
   // (conv1: K = 100, the 1x1 convolutions) are bound by exactly that traffic.
+  const int tw = (d->tune_wgrad & 0x1000) ? 0 : d->tune_wgrad;  // bit 12 = the Winograd form's own encoding (heuristics if it is switched off)
   pl.KPW = env_int("EFM_WGRAD_KPW", (ktiles >= 5) ? 2 : 1);
-  if ((d->tune_wgrad & 15) == 1 || (d->tune_wgrad & 15) == 2) pl.KPW = d->tune_wgrad & 15;
+  if ((tw & 15) == 1 || (tw & 15) == 2) pl.KPW = tw & 15;
   if (pl.KPW != 2) pl.KPW = 1;
   pl.kblocks = (ktiles + 4 * pl.KPW - 1) / (4 * pl.KPW);
   const int nb = (ntiles + 12) / 13;
@@ -948,7 +949,7 @@ WgradPlan plan_wgrad(const efm_conv_desc* d) {
   pl.nblocks = (ntiles + pl.NTW - 1) / pl.NTW;
   const int base = pl.kblocks * pl.nblocks;
   // measured on EFM-29 @ B=256: ~10 blocks per CU, but never fewer than 768 pixels (48 K steps) per block
-  const int target = (d->tune_wgrad >> 4) > 0 ? 64 * (d->tune_wgrad >> 4) : env_int("EFM_WGRAD_BLOCKS", 2560);
+  const int target = (tw >> 4) > 0 ? 64 * (tw >> 4) : env_int("EFM_WGRAD_BLOCKS", 2560);
   int splits = (target + base - 1) / base;
   const int max_splits = (M + 767) / 768;
   if (splits > max_splits) splits = max_splits;

@@ -484,7 +484,10 @@ namespace efm {
 
 // The Winograd form behind efm_conv_bwd_weight_{workspace_bytes,slabs,finish} (efm_conv.hip dispatches here when tune_wgrad has
 // bit 12): same two-launch protocol and workspace contract as the direct kernel.
-bool wino_wgrad_selected(const efm_conv_desc* d) { return (d->tune_wgrad & 0x1000) && efm_wino_supported(d); }
+bool wino_wgrad_selected(const efm_conv_desc* d) {
+  static const bool off = [] { const char* e = getenv("EFM_WINO_WGRAD"); return e && atoi(e) == 0; }();  // EFM_WINO_WGRAD=0: direct kernel always
+  return !off && (d->tune_wgrad & 0x1000) && efm_wino_supported(d);
+}
 
 size_t wino_wgrad_ws_floats(const efm_conv_desc* d) { return plan_wino_wgrad(d).ws_floats; }
 
