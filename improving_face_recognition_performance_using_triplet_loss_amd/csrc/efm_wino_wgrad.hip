@@ -206,23 +206,24 @@ __device__ __forceinline__ void ww_main_loop(const WWCtx& c, float* smem, f32x4 
   bias_rows(0);
   operands(cls, 0, 0);
   for (;;) {
-    const bool last_of_chunk = s + 1 >= ks;
-    if (last_of_chunk && ch + 1 >= c.cend) break;
-    if (last_of_chunk) {
-#ifndef EFM_WW_NOBARRIER  // (ablation build: races, timing only)
-      __syncthreads();  // the next chunk's stage has landed, and every wave holds its last operands of this one: its stage is free
-#endif
-      ks = ((gy == c.gyn - 1 ? r_last : WG_R) * (gx == c.gxn - 1 ? t_last : WG_T) + 3) >> 2;
-      cls = (gy == c.gyn - 1 ? 2 : 0) + (gx == c.gxn - 1 ? 1 : 0);
-      ++ch;
-      if (ch + 1 < c.cend) stage_chunk(buf, gy, gx);
-      buf ^= 1;
-      s = -1;
-      bias_rows(buf);
+    // a tight inner loop over the k steps of a chunk (one compare and one backward branch per step); after a chunk switch s = -1,
+    // so its first pass runs the MFMAs of the previous chunk's last step and forms the new chunk's first operands
+    while (s + 1 < ks) {
+      ++s;
+      mfmas();
+      operands(cls, s, buf);
     }
-    ++s;
-    mfmas();
-    operands(cls, s, buf);
+    if (ch + 1 >= c.cend) break;
+#ifndef EFM_WW_NOBARRIER  // (ablation build: races, timing only)
+    __syncthreads();  // the next chunk's stage has landed, and every wave holds its last operands of this one: its stage is free
+#endif
+    ks = ((gy == c.gyn - 1 ? r_last : WG_R) * (gx == c.gxn - 1 ? t_last : WG_T) + 3) >> 2;
+    cls = (gy == c.gyn - 1 ? 2 : 0) + (gx == c.gxn - 1 ? 1 : 0);
+    ++ch;
+    if (ch + 1 < c.cend) stage_chunk(buf, gy, gx);
+    buf ^= 1;
+    s = -1;
+    bias_rows(buf);
   }
   mfmas();
 }
