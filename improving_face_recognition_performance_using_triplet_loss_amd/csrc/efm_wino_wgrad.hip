@@ -7,15 +7,22 @@
 // the transformed operands: they are 4x the raw data, so an LDS stage held 4 tiles and every 48 MFMAs paid two transforms and a
 // barrier.  Here the LDS holds RAW pixels and the transform happens on the way from LDS to the MFMA operand registers:
 //   * a chunk = a 4x4 group of tiles of one image (<= 16 tiles = 4 MFMA k steps): its 10x10 input pixels x 16*CIT channels and 8x8
-//     dy pixels x 16*COT channels arrive by LDS-DMA (16 bytes per lane, no registers, no transform pass), two stages;
+//     dy pixels x 16*COT channels arrive by LDS-DMA (16 bytes per lane, whole pixel rows, no registers, no transform pass), two
+//     stages, each followed by a few zero pixels that a tile past the chunk's last one reads as dy;
 //   * block = 8 waves, one per (row i of the transform, column pair {0,1} or {2,3}): wave (i, par) owns xi = (i, 2par), (i, 2par+1),
-//     2 x COT x CIT accumulator tiles.  An operand fragment of xi is a +-1 combination of 4 (x) / 1..4 (dy) raw pixels of the
-//     lane's tile: the lane reads them with ds_read_b128 (4 channel tiles per read: MFMA row m of tile e = channel 4m + e, the
-//     same permutation on both sides of the epilogue) and combines with 2-3 FMAs whose +-1 / 0 coefficients sit in SGPRs, so all
-//     8 waves run the same code;
-//   * per k step and wave: 6 + 4 pixel reads, ~45 VALU, 2*COT*CIT MFMAs; one barrier per chunk;
-//   * epilogue: G^T . G across the waves through LDS, slabs [split][n_pad16][k_pad] exactly as the direct kernel writes them, so
-//     the fixed-order slab reduction and the bias gradient are shared.
+//     2 x COT x CIT accumulator tiles.  An operand fragment of xi is a +- combination of 4 (input) / 1..4 (dy) raw pixels of the
+//     lane's tile.  Which pixels and which signs is compile-time per wave: the main loop is instantiated 8 times (switch on the
+//     wave index; the chunk barriers pair up across the instances), so pixel offsets are immediates, the combinations are plain
+//     adds / subtracts and zero coefficients cost nothing;
+//   * MFMA tile e, row m  <->  channel N*m + e: the N values a lane needs of one pixel are N consecutive floats at one address;
+//     where the lane's tile of a k step starts in the stage comes from a 512-byte LDS table (chunk class x k step x k lane);
+//   * per k step and wave: ~20 LDS reads, ~40 VALU, 2*COT*CIT MFMAs; one barrier per chunk, placed before the MFMAs of the chunk's
+//     last k step so that the DMA of the chunk after next is issued under them;
+//   * the bias gradient rides along (the first input-channel block of a split sums the dy pixels it stages anyway);
+//   * epilogue: G^T . G across the waves through LDS, slabs [split][n_pad16][k_pad] + bias partials exactly as the direct kernel
+//     writes them: efm_conv_bwd_weight_{slabs,finish} dispatch here on bit 12 of tune_wgrad and share wgrad_reduce_k.
+// Built with -fno-slp-vectorize (build.py): packed fp32 VALU is slower than scalar VALU beside MFMAs.  Measurements, SQ counters and
+// the ablation builds behind the EFM_WW_* macros below: profiles/round2_wino_wgrad.md, DESIGN.md section 3c.
 #include <algorithm>
 #include <string.h>
 
@@ -28,7 +35,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 #define EFM_OOB 0x80000000u
 
-constexpr int WG_R = 4;                          // tile rows of a chunk (its tile columns WG_T = 4 or 8 are a kernel parameter)
+constexpr int WG_R = 4;                          // tile rows of a chunk (its tile columns WG_T are a kernel parameter: 4)
 constexpr int XR = 2 * WG_R + 2, YR = 2 * WG_R;  // staged input rows (halo of 1) / dy rows
 
 struct WinoWP {
