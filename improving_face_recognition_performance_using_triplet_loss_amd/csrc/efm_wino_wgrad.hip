@@ -204,6 +204,20 @@ __device__ __forceinline__ void ww_main_loop(const WWCtx& c, float* smem, f32x4 
   // the k steps of the block's chunks as one stream: the chunk barrier sits BEFORE the MFMAs of a chunk's last step, so that the DMA
   // of the chunk after next is issued under them
   int gy, gx;  // the chunk staged last
+#ifdef EFM_WW_STAMPS  // diagnostic build (tools/ww_ablate.sh): cycles per phase by s_memtime, printed by the waves of block 64
+  unsigned long long t_mfma = 0, t_opnd = 0, t_bar = 0, t_dma = 0, n_steps = 0, n_chunks = 0;
+  auto stamp = [&]() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+  const unsigned long long t_begin = stamp();
+#define EFM_STAMPED(acc_var, stmt) { const unsigned long long t0_ = stamp(); stmt; acc_var += stamp() - t0_; }
+#else
+#define EFM_STAMPED(acc_var, stmt) { stmt; }
+#endif
   stage_chunk(0, gy, gx);
   int ks = ((gy == c.gyn - 1 ? r_last : WG_R) * (gx == c.gxn - 1 ? t_last : WG_T) + 3) >> 2;
   int cls = (gy == c.gyn - 1 ? 2 : 0) + (gx == c.gxn - 1 ? 1 : 0);
@@ -217,22 +231,37 @@ __device__ __forceinline__ void ww_main_loop(const WWCtx& c, float* smem, f32x4 
     // so its first pass runs the MFMAs of the previous chunk's last step and forms the new chunk's first operands
     while (s + 1 < ks) {
       ++s;
-      mfmas();
-      operands(cls, s, buf);
+      EFM_STAMPED(t_mfma, mfmas());
+      EFM_STAMPED(t_opnd, operands(cls, s, buf));
+#ifdef EFM_WW_STAMPS
+      ++n_steps;
+#endif
     }
     if (ch + 1 >= c.cend) break;
 #ifndef EFM_WW_NOBARRIER  // (ablation build: races, timing only)
-    __syncthreads();  // the next chunk's stage has landed, and every wave holds its last operands of this one: its stage is free
+    EFM_STAMPED(t_bar, __syncthreads());  // the next chunk's stage has landed, and every wave holds its last operands of this one
 #endif
     ks = ((gy == c.gyn - 1 ? r_last : WG_R) * (gx == c.gxn - 1 ? t_last : WG_T) + 3) >> 2;
     cls = (gy == c.gyn - 1 ? 2 : 0) + (gx == c.gxn - 1 ? 1 : 0);
     ++ch;
-    if (ch + 1 < c.cend) stage_chunk(buf, gy, gx);
+    if (ch + 1 < c.cend) EFM_STAMPED(t_dma, stage_chunk(buf, gy, gx));
     buf ^= 1;
     s = -1;
     bias_rows(buf);
+#ifdef EFM_WW_STAMPS
+    ++n_chunks;
+#endif
   }
   mfmas();
+#ifdef EFM_WW_STAMPS
+  const unsigned long long t_total = stamp() - t_begin;
+  if (blockIdx.x == 64 && c.lane == 0)
+    printf("wave %d (row %d, columns %d): total %llu cyc; %llu k steps: mfmas %llu (%.0f/step) operands %llu (%.0f/step); %llu chunk switches: "
+           "barrier %llu (%.0f) dma %llu (%.0f)\n",
+           c.wave, WI, PAR, t_total, n_steps, t_mfma, (double)t_mfma / (double)n_steps, t_opnd, (double)t_opnd / (double)n_steps, n_chunks, t_bar,
+           (double)t_bar / (double)n_chunks, t_dma, (double)t_dma / (double)n_chunks);
+#endif
+#undef EFM_STAMPED
 }
 
 template <int COT, int CIT, int WG_T>
