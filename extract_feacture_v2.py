@@ -96,6 +96,8 @@ def main(argv=None):
         data = efm_symbol.G.Variable("data")
         feat, _ = efm_symbol.efm_feature(data)
     plan = Plan([feat], (args.batch_size, args.channels, args.image_size, args.image_size))
+    if args.batch_size >= 64 and os.environ.get("EFM_AUTOTUNE", "1") != "0":
+        plan.autotune()                                                # per-layer kernel selection, timed once
     flat = plan.new_flat()
     fc2 = None
     ckpt = os.path.join(args.model_dir, "EFM_RES.params")

@@ -90,6 +90,8 @@ def main(argv=None):
     else:
         feat_sym, _ = efm_symbol.efm_feature(efm_symbol.G.Variable("data"))
     plan = Plan([feat_sym], (2 * batch_size,) + shape, devs)          # a batch = B anchors followed by their B positives
+    if 2 * batch_size >= 64 and os.environ.get("EFM_AUTOTUNE", "1") != "0":
+        plan.autotune()                                                # per-layer kernel selection, timed once
     flat = plan.new_flat()
     if os.path.exists(ck):
         params = mxio.load_params(ck)

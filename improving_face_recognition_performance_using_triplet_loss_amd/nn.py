@@ -3,6 +3,8 @@
 import math
 
 import numpy as np
+import os
+
 import torch
 
 from . import functional as F_
@@ -90,12 +92,16 @@ class BatchNorm(torch.nn.Module):
 
 class SymbolNet(torch.nn.Module):
     """A compiled `graph.Sym` network as a torch module (the role of gluon.SymbolBlock / HybridBlock.hybridize()).
-    One flat nn.Parameter holds every weight in packed layout; plans are compiled per batch size on first use."""
+    One flat nn.Parameter holds every weight in packed layout; plans are compiled per batch size on first use.
+    autotune: time the kernel candidates of every layer once per batch size (Plan.autotune(): Winograd vs direct kernels, tilings;
+    a few seconds at training batch sizes) — None = the EFM_AUTOTUNE environment variable ("1" turns it on); batches below 64 (the
+    2-image plan that only initialises the parameters, smoke runs) are never tuned."""
 
-    def __init__(self, outputs, in_channels, image, device="cuda", seed=42, init="xavier", fuse=None):
+    def __init__(self, outputs, in_channels, image, device="cuda", seed=42, init="xavier", fuse=None, autotune=None):
         super().__init__()
         self._outputs, self.in_channels, self.image = outputs, in_channels, image
         self._fuse = fuse
+        self._autotune = (os.environ.get("EFM_AUTOTUNE", "0") == "1") if autotune is None else bool(autotune)
         self._plans = {}
         self._dev = torch.device(device)
         p0 = self.plan(2)
@@ -108,6 +114,8 @@ class SymbolNet(torch.nn.Module):
         p = self._plans.get(batch)
         if p is None:
             p = self._plans[batch] = Plan(self._outputs, (batch, self.in_channels, self.image, self.image), self._dev, fuse=self._fuse)
+            if self._autotune and batch >= 64 and self._dev.type == "cuda":
+                p.autotune()
         return p
 
     def forward(self, x):

@@ -93,7 +93,8 @@ def main(argv=None):
         root_logger.setLevel(logging.INFO)
 
     fc2_sym, feat_sym = mutli_gpu(args.classes)
-    net = SymbolNet([feat_sym], Training_IMG_channel, Training_IMG_size, device=devs, seed=42, init=None)
+    net = SymbolNet([feat_sym], Training_IMG_channel, Training_IMG_size, device=devs, seed=42, init=None,
+                    autotune=os.environ.get("EFM_AUTOTUNE", "1") != "0")   # per-layer kernel selection, timed once (batches >= 64)
     net.plan(2).init_xavier(net.flat.data, 42, magnitude=2.34, factor_type="in")          # mx.init.Xavier(factor_type="in", magnitude=2.34)
     head = torch.nn.Sequential(torch.nn.Dropout(0.7), torch.nn.Linear(342, args.classes)).to(devs)
     with torch.no_grad():

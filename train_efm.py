@@ -117,7 +117,9 @@ def main(argv=None):
     lr, MARGIN, alpha = 0.00024, 0.2, 0.1
     devs = torch.device("cuda", 0)
     print("build network...", flush=True)
-    net = LightCNN_29(args.classes, in_channels=args.channels, image=args.image_size, device=devs)
+    # kernel selection per layer is timed once per batch size (a few seconds; EFM_AUTOTUNE=0 keeps the direct kernels)
+    net = LightCNN_29(args.classes, in_channels=args.channels, image=args.image_size, device=devs,
+                      autotune=os.environ.get("EFM_AUTOTUNE", "1") != "0")
     triplet_loss = TripletLoss(margin=MARGIN)
     softmax_cross_entropy = torch.nn.CrossEntropyLoss(reduction="none")
     schedule = FactorScheduler(step=int(epoch_size * 6), factor=0.88, stop_factor_lr=5e-15)
