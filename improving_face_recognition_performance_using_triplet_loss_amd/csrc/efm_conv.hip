@@ -474,7 +474,7 @@ struct WgradP {
   int mma_blocks;
   int ktiles, ntiles;  // 16-wide tiles of the packed gradient: k_pad / 16, n_pad16 / 16
   int bias_rows;       // dy rows per column-sum block
-  int dbg;             // EFM_WGRAD_DBG (measurement only): 1 = no operand loads, 2 = no MFMA loop
+  int dbg;             // ablation builds (-DEFM_ABLATE + EFM_WGRAD_DBG): 1 = no operand loads, 2 = no MFMA loop; always 0 in the product
   unsigned x_bytes, y_bytes;
 };
 
@@ -1464,7 +1464,11 @@ int efm_conv_bwd_weight_slabs(const efm_conv_desc* d, const float* x, const floa
   float* bpart = slabs + pl.slab_floats + pl.lvl2_floats;
   p.bias_part = want_bias ? bpart : nullptr;
   p.ktiles = d->k_pad / 16; p.ntiles = d->n_pad16 / 16; p.bias_rows = BIAS_ROWS;
+#ifdef EFM_ABLATE  // measurement builds only (-DEFM_ABLATE): a production library never skips operand loads or MFMAs, whatever the environment says
   p.dbg = env_int("EFM_WGRAD_DBG", 0);
+#else
+  p.dbg = 0;
+#endif
   p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
   dim3 grid((unsigned)p.mma_blocks);  // the bias gradient rides in the k-block-0 blocks: no column-sum blocks
   int rc = (pl.KPW == 2) ? launch_wgrad_nt<2>(pl.NTW, grid, s, p) : launch_wgrad_nt<1>(pl.NTW, grid, s, p);

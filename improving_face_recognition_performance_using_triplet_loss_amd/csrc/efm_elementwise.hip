@@ -287,6 +287,7 @@ int efm_mfmb_fwd(const uint16_t* x, uint16_t* y, int64_t rows, int c, int ways, 
   const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
   const int cp_in = pad8c(c), cp_out = pad8c(cout);
   const int cw = cs + (cp_out - cout);
+  EFM_REQUIRE(rows * cw < 0x100000000L, "mfmb_fwd: more than 2^32 elements");
   dim3 grid((unsigned)efm::cdiv(rows * cw, 256));
   const __bf16* xb = reinterpret_cast<const __bf16*>(x);
   __bf16* yb = reinterpret_cast<__bf16*>(y);
@@ -305,6 +306,7 @@ int efm_mfmb_bwd(const uint16_t* x, const uint16_t* dy, const uint16_t* add, uin
   const int cs = c / ways, cout = (ways == 3) ? 2 * cs : cs;
   const int cp_in = pad8c(c), cp_out = pad8c(cout);
   const int cw = cs + (cp_in - c);
+  EFM_REQUIRE(rows * cw < 0x100000000L, "mfmb_bwd: more than 2^32 elements");
   dim3 grid((unsigned)efm::cdiv(rows * cw, 256));
   const __bf16 *xb = reinterpret_cast<const __bf16*>(x), *gb = reinterpret_cast<const __bf16*>(dy), *ab = reinterpret_cast<const __bf16*>(add);
   __bf16* db = reinterpret_cast<__bf16*>(dx);

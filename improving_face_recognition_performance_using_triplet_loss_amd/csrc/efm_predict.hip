@@ -118,7 +118,13 @@ bool add_conv(Predictor& P, const std::map<std::string, Blob>& params, const std
               int mode, int order, const float* residual) {
   auto wi = params.find(name + "_weight"), bi = params.find(name + "_bias");
   if (wi == params.end() || bi == params.end()) {
-    efm::set_error("pred_create: parameter %s_weight / _bias missing", name.c_str());
+    // say which graph this predictor binds: a Gluon checkpoint (structural keys, shared convolutions) is a different network
+    std::string first = params.empty() ? std::string("<none>") : params.begin()->first;
+    efm::set_error("pred_create: parameter %s_weight / _bias missing. This predictor binds the Symbol EFM-29 of efm_symbol.py:81-101 "
+                   "(parameters conv1, conv{L}{x}_res, conv{L}{x}_res_r, conv{L}_r, conv{L}, fc1 — the checkpoints mutli_gpu_v3.py / "
+                   "Feature.hpp use); the blob holds %zu arrays, e.g. '%s' — a Gluon LightCNN_29 checkpoint of train_efm.py "
+                   "(conv_net.N.conv_op_K.weight, shared convolutions, Dense(1026)) is a different graph and is not served here",
+                   name.c_str(), params.size(), first.c_str());
     return false;
   }
   Op op;

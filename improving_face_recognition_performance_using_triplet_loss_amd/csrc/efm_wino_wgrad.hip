@@ -545,7 +545,11 @@ int wino_wgrad_slabs(const efm_conv_desc* d, const float* x, const float* dy, in
   p.cob = pl.cob; p.cib = pl.cib; p.splits = pl.splits; p.cps = pl.cps;
   p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * d->cin_p * 4);
   p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * d->cout_p * 4);
+#ifdef EFM_ABLATE  // measurement builds only (-DEFM_ABLATE): a production library never skips loads or MFMAs, whatever the environment says
   { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
+  p.dbg = 0;
+#endif
   const int blocks = pl.cob * pl.cib * pl.splits;
   switch (kShapes[pl.shape].cot * 256 + kShapes[pl.shape].cit * 16 + kShapes[pl.shape].tt) {
 #define EFM_CASE(A, B, T) case A * 256 + B * 16 + T: launch<A, B, T>(p, blocks, s); break;

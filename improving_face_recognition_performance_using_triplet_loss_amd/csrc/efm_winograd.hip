@@ -646,7 +646,11 @@ int run_wino(const float* x, const float* u, const float* bias, const float* res
   p.kpad = pl.kpad; p.chunks = pl.kpad / (pl.variant == 4 ? KC4 : KC); p.nblocks = pl.nblocks;
   p.x_bytes = (unsigned)((size_t)batch * h * w * cin_p * 4);
   p.u_bytes = (unsigned)((size_t)16 * pl.n_rows * pl.kpad * 4);
+#ifdef EFM_ABLATE  // measurement builds only (-DEFM_ABLATE): a production library never skips loads or MFMAs, whatever the environment says
   { const char* e = getenv("EFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
+#else
+  p.dbg = 0;
+#endif
   dim3 grid((unsigned)(efm::cdiv(p.tiles, TB) * pl.nblocks));
   if (pl.variant == 4) {
     if (pl.NTB == 3) hipLaunchKernelGGL((wino4_k<3>), grid, dim3(256), 0, s, p);

@@ -28,6 +28,7 @@ class BucketReducer:
         self._handles = []
         self.launch_order = []
         self.last_launch_order = []
+        self.last_collectives = 0   # all-reduces actually issued by the last finished step (0 with one rank and no force)
         self.reset()
 
     @staticmethod
@@ -77,5 +78,6 @@ class BucketReducer:
             raise RuntimeError("buckets %s never became ready" % missing)
         for h in self._handles:
             h.wait()
+        self.last_collectives = len(self._handles)
         self.last_launch_order = list(self.launch_order)
         self.reset()

@@ -207,32 +207,140 @@ def read_record_at(f, off, length):
             return struct.pack("<I", _REC_MAGIC).join(parts)
 
 
+def pread_record_at(fd, off, length):
+    """`read_record_at` on a file DESCRIPTOR with positional reads (os.pread): no shared file position, so the decode workers of
+    `ImageRecordIter` read concurrently from one descriptor."""
+    import os
+    if length >= 0:
+        return os.pread(fd, length, off + 8)
+    parts = []
+    while True:
+        magic, lrec = struct.unpack("<II", os.pread(fd, 8, off))
+        cflag, ln = lrec >> 29, lrec & ((1 << 29) - 1)
+        parts.append(os.pread(fd, ln, off + 8))
+        off += 8 + ln + (4 - ln % 4) % 4
+        if cflag == 3:
+            return struct.pack("<I", _REC_MAGIC).join(parts)
+
+
+_WORKER_FD = {}
+
+
+def _decode_slice(task):
+    """Body of a decode-pool worker (decode_worker.py, a separate PROCESS: PIL holds the GIL for about half of a small image's decode, so threads convoy):
+    task = (path, [(offset, length)...], gray) -> ([label...], uint8 array (n, H, W[, C]) when all images share one size, else a list)."""
+    import os
+    path, entries, gray = task
+    fd = _WORKER_FD.get(path)
+    if fd is None:
+        fd = _WORKER_FD[path] = os.open(path, os.O_RDONLY)
+    labels, imgs = [], []
+    for off, length in entries:
+        label, _, img = unpack_img(pread_record_at(fd, off, length), gray=gray)
+        labels.append(float(np.atleast_1d(label)[0]))
+        imgs.append(img)
+    if len({im.shape for im in imgs}) == 1:
+        imgs = np.stack(imgs)
+    return labels, imgs
+
+
+class _DecodePool:
+    """N decode_worker child processes (plain subprocesses over pipes: no multiprocessing start-method pitfalls, no re-import of the
+    caller's script, nothing inherited from a GPU-initialised parent).  map() hands task i to worker i and collects in order."""
+
+    def __init__(self, n):
+        import os
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+        self.procs = [subprocess.Popen([sys.executable, "-m", __package__ + ".decode_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       env=env, cwd=root) for _ in range(n)]
+
+    def map(self, tasks):
+        import pickle
+        assert len(tasks) <= len(self.procs)
+        for p, t in zip(self.procs, tasks):
+            pickle.dump(t, p.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+            p.stdin.flush()
+        out = []
+        for p, _ in zip(self.procs, tasks):
+            try:
+                r = pickle.load(p.stdout)
+            except EOFError:
+                raise RuntimeError("decode worker died (exit code %s)" % p.poll())
+            if isinstance(r, BaseException):
+                raise r
+            out.append(r)
+        return out
+
+    def close(self):
+        import pickle
+        for p in self.procs:
+            try:
+                pickle.dump(None, p.stdin)
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+        self.procs = []
+
+
 class ImageRecordIter:
     """mx.io.ImageRecordIter(path_imgrec, data_shape=(C,H,W), batch_size, scale, rand_crop, rand_mirror, shuffle, part_index,
-    num_parts) stand-in (ref: train_efm.py:179-181): emits NCHW float32 batches scaled by `scale`; images larger than (H, W)
-    are randomly (or centre-) cropped, smaller ones are an error; the last partial batch is dropped.
+    num_parts, preprocess_threads, prefetch_buffer) stand-in (ref: train_efm.py:179-181): emits NCHW float32 batches scaled by
+    `scale`; images larger than (H, W) are randomly (or centre-) cropped, smaller ones are an error; the last partial batch is dropped.
 
     Streaming: __init__ only indexes the record headers (16 bytes of host memory per image — the reference's 4.6 M-image set is
     74 MB of index, not 80 GB of decoded pixels); a batch is decoded, cropped and mirrored when it is asked for, with a fresh
-    crop / mirror / order every epoch, as MXNet's iterator does.  `part_index` / `num_parts` (MXNet's own parameters for
-    distributed reading) give each data-parallel rank a disjoint 1/num_parts of the records, so that one epoch covers the data
-    set once however many ranks read it."""
+    crop / mirror / order every epoch, as MXNet's iterator does.
+
+    Parallel like MXNet's C++ iterator (its `preprocess_threads` / `prefetch_buffer` parameters): a producer thread assembles
+    batches AHEAD of the consumer — the records of a batch are read (positional reads) and decoded by a pool of
+    `preprocess_threads` worker PROCESSES, each taking a contiguous slice of the batch (processes, not threads: for face-sized
+    images PIL holds the GIL for about half of a decode and a thread pool runs slower than one thread — measured); 1 = decode on
+    the producer thread itself.  The crop / mirror draws are then taken sequentially in record order, exactly the draws of the
+    synchronous path, so the batches are bit-identical to it whatever the worker count.  With
+    `device=` the decoded uint8 images go into a pinned staging buffer and cross PCIe on a copy stream while the previous step is
+    still computing; `efm_crop_mirror_u8` (crop, mirror, scale, uint8 -> fp32 NCHW) then runs on the consumer's stream.
+    `preprocess_threads=0` is the synchronous path (decode on the calling thread when the batch is asked for).
+
+    `part_index` / `num_parts` (MXNet's own parameters for distributed reading) give each data-parallel rank a disjoint share of
+    the records.  Every share holds EXACTLY n // num_parts records (the n % num_parts records at the end are not read this
+    epoch by anyone): ranks that all-reduce once per batch must see the same number of batches, or the rank with one more blocks
+    forever in its collective."""
 
     def __init__(self, path_imgrec, data_shape, batch_size, scale=1.0, rand_crop=False, rand_mirror=False, shuffle=False, seed=0,
-                 part_index=0, num_parts=1, device=None, **_):
+                 part_index=0, num_parts=1, device=None, preprocess_threads=None, prefetch_buffer=2, **_):
+        import os
         if not 0 <= part_index < num_parts:
             raise ValueError("part_index %d outside [0, %d)" % (part_index, num_parts))
         self.path, self.data_shape, self.batch_size, self.scale = path_imgrec, tuple(data_shape), batch_size, scale
         self.rand_crop, self.rand_mirror, self.shuffle = rand_crop, rand_mirror, shuffle
         index = index_records(path_imgrec)
         n = len(index)
-        self.index = index[part_index * n // num_parts: (part_index + 1) * n // num_parts]   # contiguous chunk, like MXNet's partition
+        share = n // num_parts                                       # equal shares: equal batch counts on every rank
+        self.index = index[part_index * share: (part_index + 1) * share]   # contiguous chunk, like MXNet's partition
         self.num_total = n
         self._rng = np.random.default_rng(seed)
         # device: crop / mirror / scale / uint8 -> fp32 run on the GPU (efm_crop_mirror_u8) and the batch is born there: the host only
         # decodes, and 4x fewer bytes cross PCIe.  Same random draws in the same order as the host path: bit-identical batches.
         self.device = device
-        self._file = None
+        if preprocess_threads is None:
+            preprocess_threads = int(os.environ.get("EFM_DECODE_THREADS", min(16, os.cpu_count() or 1)))
+        self.threads = max(0, int(preprocess_threads))
+        self.prefetch = max(1, int(prefetch_buffer))
+        self._fd = None
+        self._pool = None
+        self._producer = None
+        self._queue = None
+        self._stop = None
+        self._copy_stream = None
+        self._staging = {}
         self._order = np.arange(len(self.index))
         self.epoch = -1
         self.reset()
@@ -244,24 +352,137 @@ class ImageRecordIter:
         self.reset()
         return self
 
-    def _read(self, k):
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def close(self):
+        import os
+        self._stop_producer()
+        if self._pool is not None:
+            self._pool.close()
+            self._pool = None
+        if self._fd is not None:
+            os.close(self._fd)
+            self._fd = None
+
+    # ---- one record: read + decode (any thread), then its crop / mirror draws (sequential, in record order)
+    def _load(self, k):
         c, h, w = self.data_shape
-        label, _, img = unpack_img(read_record_at(self._file, *self.index[k]), gray=(c == 1))
+        label, _, img = unpack_img(pread_record_at(self._fd, *self.index[k]), gray=(c == 1))
         ih, iw = img.shape[:2]
         if ih < h or iw < w:
             raise ValueError("record image %dx%d smaller than data_shape %dx%d" % (ih, iw, h, w))
+        return img, float(np.atleast_1d(label)[0])
+
+    def _draw(self, img):
+        c, h, w = self.data_shape
+        ih, iw = img.shape[:2]
         y0 = int(self._rng.integers(0, ih - h + 1)) if self.rand_crop else (ih - h) // 2
         x0 = int(self._rng.integers(0, iw - w + 1)) if self.rand_crop else (iw - w) // 2
         flip = bool(self.rand_mirror and self._rng.random() < 0.5)
-        return img, (y0, x0, flip), float(np.atleast_1d(label)[0])
+        return y0, x0, flip
 
-    def _decode(self, k):
+    def _assemble(self, pos):
+        """Batch starting at `pos` of the epoch order -> a host-side item: ("dev", pinned uint8 (B, IH, IW, C), crops, labels, event)
+        when the GPU does the cropping, else ("host", uint8 (B, C, H, W), labels)."""
+        import os
+
+        import torch
+        if self._fd is None:
+            self._fd = os.open(self.path, os.O_RDONLY)
         c, h, w = self.data_shape
-        img, (y0, x0, flip), label = self._read(k)
-        img = img[y0:y0 + h, x0:x0 + w]
-        if flip:
-            img = img[:, ::-1]
-        return (img[None] if c == 1 else img.transpose(2, 0, 1)), label
+        ks = [int(self._order[pos + j]) for j in range(self.batch_size)]
+        if self.threads > 1:
+            if self._pool is None:
+                self._pool = _DecodePool(self.threads)
+            per = -(-self.batch_size // self.threads)
+            tasks = [(self.path, [self.index[k] for k in ks[i:i + per]], c == 1) for i in range(0, self.batch_size, per)]
+            loaded = []
+            for labels_s, imgs_s in self._pool.map(tasks):
+                loaded += [(im, lb) for im, lb in zip(imgs_s, labels_s)]
+            for im, _ in loaded:
+                if im.shape[0] < h or im.shape[1] < w:
+                    raise ValueError("record image %dx%d smaller than data_shape %dx%d" % (im.shape[0], im.shape[1], h, w))
+        else:
+            loaded = [self._load(k) for k in ks]
+        labels = np.array([lb for _, lb in loaded], dtype=np.float32)
+        crops = np.empty((self.batch_size, 3), dtype=np.int32)
+        for j, (img, _) in enumerate(loaded):
+            crops[j] = self._draw(img)
+        imgs = [img if img.ndim == 3 else img[:, :, None] for img, _ in loaded]
+        if self.device is not None and len({im.shape for im in imgs}) == 1:
+            # one source size per batch (the usual pre-resized .rec): the GPU path.  Pinned staging buffers rotate; a buffer is
+            # rewritten only after the copy that read it has finished (its event).
+            shape = (self.batch_size,) + imgs[0].shape
+            slot = self._slot = (getattr(self, "_slot", -1) + 1) % (self.prefetch + 2)
+            st = self._staging.get(slot)
+            if st is None or tuple(st[0].shape) != shape:
+                st = self._staging[slot] = [torch.empty(shape, dtype=torch.uint8).pin_memory(), torch.empty((self.batch_size, 3), dtype=torch.int32).pin_memory(), None]
+            if st[2] is not None:
+                st[2].synchronize()
+            np.stack(imgs, out=st[0].numpy())
+            st[1].numpy()[:] = crops
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._copy_stream):
+                src = st[0].to(self.device, non_blocking=True)
+                crop_d = st[1].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            st[2] = ev
+            return ("dev", src, crop_d, labels, ev)
+        data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)   # host crop (no device, or mixed source sizes): same draws
+        for j, (im, (y0, x0, flip)) in enumerate(zip(imgs, crops)):
+            im = im[y0:y0 + h, x0:x0 + w]
+            data[j] = (im[:, ::-1] if flip else im).transpose(2, 0, 1)
+        return ("host", data, labels)
+
+    # ---- producer thread: batches of the current epoch, at most `prefetch` ahead of the consumer
+    def _produce(self, first_pos, q, stop):
+        try:
+            pos = first_pos
+            while pos + self.batch_size <= len(self.index) and not stop.is_set():
+                state = self._rng.bit_generator.state      # lets a mid-epoch reset() hand back the draws of unconsumed batches
+                item = self._assemble(pos)
+                pos += self.batch_size
+                while not stop.is_set():
+                    try:
+                        q.put((item, state), timeout=0.05)
+                        break
+                    except Exception:
+                        continue
+            q_put_forever(q, (None, None), stop)
+        except BaseException as e:  # surfaces in the consumer
+            q_put_forever(q, (e, None), stop)
+
+    def _start_producer(self):
+        import queue
+        import threading
+        self._queue = queue.Queue(maxsize=self.prefetch)
+        self._stop = threading.Event()
+        self._producer = threading.Thread(target=self._produce, args=(self.pos, self._queue, self._stop), name="efm-record-iter", daemon=True)
+        self._producer.start()
+
+    def _stop_producer(self):
+        """Stop the producer and give the random stream back the draws of every batch that was assembled but never consumed."""
+        if self._producer is None:
+            return
+        self._stop.set()
+        first_unconsumed = None
+        while self._producer.is_alive() or not self._queue.empty():
+            try:
+                item, state = self._queue.get(timeout=0.05)
+            except Exception:
+                continue
+            if first_unconsumed is None and state is not None:
+                first_unconsumed = state
+        self._producer.join()
+        self._producer = None
+        if first_unconsumed is not None:
+            self._rng.bit_generator.state = first_unconsumed
 
     def __next__(self):
         import torch
@@ -269,30 +490,30 @@ class ImageRecordIter:
         from .data import Batch
         if self.pos + self.batch_size > len(self.index):
             raise StopIteration
-        if self._file is None:
-            self._file = open(self.path, "rb")
         c, h, w = self.data_shape
-        labels = np.empty((self.batch_size,), dtype=np.float32)
-        if self.device is not None:
-            imgs, crops = [], np.empty((self.batch_size, 3), dtype=np.int32)
-            for j in range(self.batch_size):
-                img, crops[j], labels[j] = self._read(int(self._order[self.pos + j]))
-                imgs.append(img if img.ndim == 3 else img[:, :, None])
-            if len({im.shape for im in imgs}) == 1:      # one source size per batch (the usual pre-resized .rec): the GPU path
-                from . import ops
-                self.pos += self.batch_size
-                src = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).to(self.device, non_blocking=True)
-                x = ops.crop_mirror_u8(src, torch.from_numpy(crops).to(self.device, non_blocking=True), h, w, self.scale)
-                return Batch(["data"], [x], ["softmax_label"], [torch.from_numpy(labels)])
-            data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)   # mixed sizes: crop on the host, same draws
-            for j, (im, (y0, x0, flip)) in enumerate(zip(imgs, crops)):
-                im = im[y0:y0 + h, x0:x0 + w]
-                data[j] = (im[:, ::-1] if flip else im).transpose(2, 0, 1)
+        if self.threads > 0:
+            if self._producer is None:
+                self._start_producer()
+            item, _ = self._queue.get()
+            if isinstance(item, BaseException):
+                self._producer.join()
+                self._producer = None
+                raise item
+            if item is None:
+                raise StopIteration
         else:
-            data = np.empty((self.batch_size, c, h, w), dtype=np.uint8)
-            for j in range(self.batch_size):
-                data[j], labels[j] = self._decode(int(self._order[self.pos + j]))
+            item = self._assemble(self.pos)
         self.pos += self.batch_size
+        if item[0] == "dev":
+            from . import ops
+            _, src, crop_d, labels, ev = item
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            src.record_stream(cur)
+            crop_d.record_stream(cur)
+            x = ops.crop_mirror_u8(src, crop_d, h, w, self.scale)
+            return Batch(["data"], [x], ["softmax_label"], [torch.from_numpy(labels)])
+        _, data, labels = item
         x = torch.from_numpy(data).to(torch.float32)
         if self.scale != 1.0:
             x *= self.scale
@@ -303,10 +524,20 @@ class ImageRecordIter:
     next = __next__
 
     def reset(self):
+        self._stop_producer()
         self.pos = 0
         self.epoch += 1
         if self.shuffle:
             self._order = self._rng.permutation(len(self.index))
+
+
+def q_put_forever(q, item, stop):
+    while not stop.is_set():
+        try:
+            q.put(item, timeout=0.05)
+            return
+        except Exception:
+            continue
 
 
 # ---------------------------------------------------------------------------------------------------------------------

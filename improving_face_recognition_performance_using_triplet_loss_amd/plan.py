@@ -280,7 +280,8 @@ class Plan:
                 if getattr(st, "u_dgrad", None) is None or st.u_dgrad.numel() != n:
                     st.u_dgrad = torch.empty((n,), dtype=torch.float32, device=self.device)
                 jobs.append((st.desc, w, st.u_dgrad, True, 0))
-        self._u_dgrad_ready = bool(train)
+        # an inference forward between a training forward and its backward leaves the data-gradient U in place (same weights)
+        self._u_dgrad_ready = bool(train) or self._u_dgrad_ready
         ops.wino_make_u_batch(jobs)
 
     # --------------------------------------------------------------------------- parameters
@@ -404,7 +405,8 @@ class Plan:
                                                          ops._stream()), "efm_l2norm_fwd")
                 acts[st.index] = y
                 aux[st.index] = norm
-        self._acts, self._aux = (acts, aux) if train else (None, None)
+        if train:  # an inference forward (same-batch evaluation inside a step) leaves the saved state of the training forward alone
+            self._acts, self._aux = acts, aux
         outs = []
         for st in self.outputs:
             t = acts[st.index]

@@ -30,12 +30,13 @@ def main():
     tr = TripletTrainer(batch, image=image, seed=3, optimizer="sgd", lr=0.05, wd=1e-5)
     assert tr.world == 2
     x, neg = shard_inputs(rank, batch, image)
-    losses, flats = [], []
+    losses, flats, grads = [], [], []
     for _ in range(steps):
         losses.append(tr.step(x, neg).clone())
         flats.append(tr.flat.cpu())
+        grads.append(tr.grad.cpu())   # the all-reduced (summed over ranks) flat gradient of this step
     torch.cuda.synchronize()
-    torch.save({"flat": tr.flat.cpu(), "flats": torch.stack(flats), "grad": tr.grad.cpu(), "loss": torch.stack(losses).cpu(),
+    torch.save({"flat": tr.flat.cpu(), "flats": torch.stack(flats), "grad": tr.grad.cpu(), "grads": torch.stack(grads), "loss": torch.stack(losses).cpu(),
                 "order": tr.reducer.last_launch_order, "nbuckets": len(tr.reducer.bounds) - 1}, os.path.join(out, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

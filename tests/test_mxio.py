@@ -2,6 +2,7 @@
 import struct
 
 import numpy as np
+import torch
 
 from improving_face_recognition_performance_using_triplet_loss_amd import mxio
 
@@ -136,14 +137,15 @@ def test_recordio_byte_level_known_answer(tmp_path):
 
 def test_image_record_iter_streams_and_shards(tmp_path):
     """ImageRecordIter keeps an index, not pixels; `part_index` / `num_parts` (MXNet's parameters) give data-parallel ranks disjoint
-    shares that together cover the file once; crops / mirrors / order are redrawn every epoch."""
+    shares of EQUAL size (n // num_parts records each: ranks that all-reduce per batch must step the same number of times);
+    crops / mirrors / order are redrawn every epoch."""
     rng = np.random.default_rng(2)
     imgs = [rng.integers(0, 256, size=(20, 20), dtype=np.uint8) for _ in range(10)]
     path = str(tmp_path / "d.rec")
     mxio.write_records(path, [mxio.pack_img(float(i), i, im) for i, im in enumerate(imgs)])
     parts = [mxio.ImageRecordIter(path, (1, 20, 20), batch_size=1, part_index=k, num_parts=3) for k in range(3)]
     seen = [[int(b.label[0][0]) for b in p] for p in parts]
-    assert sorted(sum(seen, [])) == list(range(10)) and [len(s) for s in seen] == [3, 3, 4]
+    assert sum(seen, []) == list(range(9)) and [len(s) for s in seen] == [3, 3, 3]
     assert all(p.num_total == 10 for p in parts) and not hasattr(parts[0], "data_arr")
     it = mxio.ImageRecordIter(path, (1, 16, 16), batch_size=5, rand_crop=True, rand_mirror=True, shuffle=True, seed=1)
     e1 = [b.label[0].tolist() for b in it]
@@ -151,3 +153,44 @@ def test_image_record_iter_streams_and_shards(tmp_path):
     assert sorted(sum(e1, [])) == sorted(sum(e2, [])) == [float(i) for i in range(10)] and e1 != e2
     full = next(iter(mxio.ImageRecordIter(path, (1, 20, 20), batch_size=10, scale=1.0 / 255)))
     assert np.allclose(full.data[0][3, 0].numpy() * 255, imgs[3])
+
+
+def test_image_record_iter_equal_batches_per_rank(tmp_path):
+    """1025 records over 2 ranks at local batch 171 (the advisor's case: 512 vs 513 records gave 2 vs 3 batches, and the rank with
+    the extra batch would block forever in its all-reduce): every rank yields the same number of batches."""
+    img = np.zeros((4, 4), dtype=np.uint8)
+    path = str(tmp_path / "n.rec")
+    mxio.write_records(path, [mxio.pack_img(float(i), i, img) for i in range(1025 + 2)])
+    for n_parts, bs in ((2, 171), (3, 114), (8, 64)):
+        its = [mxio.ImageRecordIter(path, (1, 4, 4), batch_size=bs, part_index=k, num_parts=n_parts, preprocess_threads=0) for k in range(n_parts)]
+        counts = [sum(1 for _ in it) for it in its]
+        assert len(set(counts)) == 1 and counts[0] == (1027 // n_parts) // bs, (n_parts, bs, counts)
+        assert len({len(it) for it in its}) == 1
+
+
+def test_image_record_iter_threaded_prefetch_is_bit_identical_to_synchronous(tmp_path):
+    """The decode pool + one-batch-ahead producer (MXNet's `preprocess_threads` / `prefetch_buffer`, ref: train_efm.py:179-181 is a
+    threaded C++ iterator) must emit exactly the batches of the synchronous path: decoding is parallel, the crop / mirror draws
+    stay sequential in record order.  Also across epochs (reshuffle) and across a reset() in the middle of an epoch, where the
+    producer has already drawn for batches nobody consumed."""
+    rng = np.random.default_rng(5)
+    path = str(tmp_path / "t.rec")
+    mxio.write_records(path, [mxio.pack_img(float(i), i, rng.integers(0, 256, size=(24, 28), dtype=np.uint8), fmt="PNG") for i in range(70)])
+    kw = dict(batch_size=8, scale=1.0 / 255, rand_crop=True, rand_mirror=True, shuffle=True, seed=9)
+    sync = mxio.ImageRecordIter(path, (1, 16, 16), preprocess_threads=0, **kw)
+    thr = mxio.ImageRecordIter(path, (1, 16, 16), preprocess_threads=4, prefetch_buffer=3, **kw)
+
+    def take(it, n):
+        out = []
+        for b in it:
+            out.append((b.data[0].clone(), b.label[0].clone()))
+            if len(out) == n:
+                break
+        return out
+
+    for n in (100, 3, 100):      # a whole epoch, an epoch abandoned after 3 batches, another whole epoch
+        a, b = take(sync, n), take(thr, n)
+        assert len(a) == len(b) == min(n, 8)
+        for (xa, la), (xb, lb) in zip(a, b):
+            assert torch.equal(xa, xb) and torch.equal(la, lb)
+    thr.close()

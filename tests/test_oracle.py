@@ -353,3 +353,26 @@ def test_lightcnn29_restatements_agree_and_reproduce_fixture():
     r2 = O.train_efm_step(p2, x, labels, neg, M.MARGIN, 0.0)
     pred = (r["grads"]["g4_res_conv1_weight"] * dw).sum()
     assert abs((r2["loss"].sum() - r["loss"].sum()) - pred) < 1e-3 * abs(pred) + 1e-12
+
+
+def test_host_loops_restatement_agrees_with_the_vectorised_forms():
+    """oracle/host_loops.py (the reference's literal per-sample loops, train_efm.py:234-239 and :26-34, the thing bench.py's
+    `host_loops` leg times) against the vectorised statements of the same arithmetic: every picked negative has another label,
+    the copied rows are the indexed rows, the cosine lists equal the row-wise formula."""
+    import random
+
+    import torch
+
+    from oracle import host_loops as H
+    b, d = 24, 16
+    lab = (torch.arange(b) % 6).to(torch.float32)
+    lab2 = torch.cat([lab, lab])
+    fc = torch.as_tensor(np.random.default_rng(3).uniform(-1, 1, size=(2 * b, d)), dtype=torch.float32)
+    neg, idx = H.pick_negatives_loop(lab2, fc, b, random.Random(7))
+    assert all(int(lab2[j]) != int(lab2[i]) and 0 <= j < b for i, j in enumerate(idx))
+    assert torch.equal(neg, fc[torch.tensor(idx)])
+    pd, nd = H.cosine_dist_loop(fc[:b], fc[b:], neg, b)
+    rows = H.csv_rows(pd, nd, b)
+    cos = torch.nn.functional.cosine_similarity
+    assert np.allclose([r[0] for r in rows], cos(fc[:b], fc[b:]).numpy(), atol=1e-6)
+    assert np.allclose([r[1] for r in rows], cos(fc[:b], neg).numpy(), atol=1e-6)

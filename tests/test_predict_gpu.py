@@ -92,3 +92,24 @@ def test_predictor_single_image_graph_replay(tmp_path, monkeypatch):
     assert not np.array_equal(outs["1"][0], outs["1"][1])          # the replay reads the new input, not a baked-in one
     print("single-image forward: %.3f ms plain launches, %.3f ms graph replay" % (times["0"] * 1e3, times["1"] * 1e3))
     assert times["1"] < 1.2 * times["0"]
+
+
+def test_predictor_refuses_a_gluon_checkpoint_and_names_the_expected_graph(tmp_path):
+    """The predictor binds the Symbol EFM-29 (what Feature.hpp loads).  The `efm_res-%04d.params` of train_efm.py holds the Gluon
+    LightCNN_29 (structural keys, shared convolutions): creation fails with a message that names the missing Symbol parameter and
+    the graph it expected — not a crash, not a silently wrong network."""
+    import lightcnn
+    from improving_face_recognition_performance_using_triplet_loss_amd import _lib
+    net = lightcnn.LightCNN_29(16, in_channels=1, image=32)
+    path = str(tmp_path / "efm_res-0001.params")
+    net.save_parameters(path)
+    blob = open(path, "rb").read()
+    lib = _lib.load()
+    keys = (ctypes.c_char_p * 1)(b"data")
+    indptr = (ctypes.c_uint32 * 2)(0, 4)
+    shape = (ctypes.c_uint32 * 4)(1, 1, 128, 128)
+    h = ctypes.c_void_p()
+    rc = lib.efm_pred_create(None, blob, len(blob), 0, 1, keys, indptr, shape, ctypes.byref(h))
+    assert rc != 0 and not h.value
+    msg = lib.efm_last_error_string().decode()
+    assert "conv1_weight" in msg and "Symbol EFM-29" in msg and "Gluon" in msg, msg

@@ -158,3 +158,42 @@ def test_tuned_plan_vs_config1_golden():
     assert rel_err(loss.cpu().numpy(), z["loss"]) < 1e-3
     dl, dr = loss.cpu().numpy() - 0.2, z["loss"] - 0.2
     assert np.abs(dl - dr).max() < 1e-3 * np.abs(dr).max() + 1e-7
+
+
+def test_tuned_kernels_gradients_vs_fp64_oracle_with_route_handover():
+    """The benchmarked selection against the fp64 oracle DIRECTLY (not through the direct kernels): 8 images of 3x112x112 — every
+    real map size, the 7 -> 3 floor pooling — on a plan that applies the committed table with one kernel per graph node (so that
+    the MFM / pooling inputs exist for the route hand-over, as in test_e2e_gpu.py::test_112_step_vs_oracles): the 3x3 forwards
+    and data gradients run wino4_k / wino_fwd_k, the weight gradients wino_wgrad_k.  Embeddings / loss and all 62 parameter
+    gradients <= 1e-3 (north_star's tolerance) with the oracle following the device's arg-max routes."""
+    from oracle import efm_oracle as O
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops, synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    batch, image = 8, IMAGE
+    shapes = O.efm29_param_shapes(3, image)
+    params = O.init_params(shapes, 42)
+    w_head = O.uniform_pm((128, 342), 777, O.xavier_uniform_scale((128, 342)))
+    x = O.uniform01(batch * 3 * image * image, 1234).reshape(batch, 3, image, image)
+    tr = TripletTrainer(batch, image=image, optimizer="sgd", lr=0.05, wd=1e-5, fuse=False, tuning=_table())
+    convs = [s for s in tr.plan.steps if s.op == "conv"]
+    assert sum(bool(s.wino_fwd) for s in convs) >= 20 and sum(bool(s.wino_dgrad) for s in convs) >= 20
+    assert sum(bool(ops.conv_kernel_info(s.desc, ops.PASS_WGRAD)[0].startswith("wino_wgrad_k")) for s in convs) >= 20
+    allp = dict(params)
+    allp["head_weight"] = w_head
+    tr.plan.load_params(tr.flat, allp)
+    neg = synth.negative_indices(synth.parity_labels(batch, images_per_identity=2), 99)
+    demb = np.random.default_rng(6).uniform(-1, 1, size=(batch, 128))
+    loss = tr.forward_loss(torch.as_tensor(x, dtype=torch.float32).cuda(), neg.cuda())
+    routing = {k: v.cpu().numpy().astype(np.float64) for k, v in tr.plan.routing_inputs().items()}
+    tr.backward(demb=torch.as_tensor(demb, dtype=torch.float32).cuda())
+    g = tr.plan.export_params(tr.grad)
+    loss_r, emb_r, _, grads_r, ghead_r = O.train_step_loss(params, w_head, x, neg.numpy(), 0.2, demb=demb, routing=routing)
+    assert rel_err(tr.last["emb"].cpu().numpy(), emb_r) < 1e-3 and rel_err(loss.cpu().numpy(), loss_r) < 1e-3
+    worst, worst_name = 0.0, None
+    for name, r in grads_r.items():
+        e = rel_err(g[name].cpu().numpy().reshape(r.shape), r)
+        if e > worst:
+            worst, worst_name = e, name
+    print("tuned (Winograd) kernels vs fp64 oracle, same routes: %d gradients, worst %.3e (%s)" % (len(grads_r), worst, worst_name))
+    assert len(grads_r) == 62 and worst < 1e-3, (worst, worst_name)
+    assert rel_err(g["head_weight"].cpu().numpy().reshape(128, 342), ghead_r) < 1e-3
