@@ -186,6 +186,46 @@ def dominant_kernel_roofline(trainer, torch, iters=3):
             "mfma_flop_executed_per_step": sum(f["mfma_flop"] for f in fam.values()), "families": table[:8]}
 
 
+def step_bound(plan, peak_tflops, hbm_tbs=8.0):
+    """SURVEY.md §8d's per-layer bound of one training step of `plan`: for every convolution and pass (forward, data gradient, weight
+    gradient) max(t_flops, t_bytes) with t_flops = unpadded 2*M*cout*cin*kh*kw / MFMA peak of the plan's dtype and t_bytes = the
+    pass's ALGORITHMIC HBM bytes / 8 TB/s — every operand once: the layer's input, its stored output (for a fused conv -> MFM [-> pool]
+    layer that is z + one route byte per element, NOT the full-resolution conv output: a design that materialises the conv-output
+    gradient moves more than this bound prices) and the weights.  Returns the sums and which side governs."""
+    es_act = 2 if plan.dtype == "bf16" else 4
+    t_f = t_b = t_max = 0.0
+    layers = []
+    for st in plan.steps:
+        if st.op != "conv":
+            continue
+        d = st.desc
+        f32 = getattr(st, "f32", False) or plan.dtype != "bf16"
+        es = 4 if f32 else es_act
+        pad = (lambda c: (c + 3) // 4 * 4) if es == 4 else (lambda c: (c + 7) // 8 * 8)
+        m = d.batch * d.hout * d.wout
+        fl = 2.0 * m * d.cout * d.cin * d.kh * d.kw
+        xb = d.batch * d.hin * d.win * pad(d.cin) * es
+        if st.epi is not None:
+            co = d.cout // 2 if st.epi["ways"] == 2 else 2 * d.cout // 3
+            zp = d.batch * (d.hout // 2) * (d.wout // 2) if st.epi["pool"] else m
+            zb = zp * pad(co) * (es + 1)
+        else:
+            zb = m * pad(d.cout) * es
+        wn = d.cout * d.cin * d.kh * d.kw
+        peak = (157.3 if f32 else peak_tflops) * 1e12
+        passes = [("fwd", xb + zb + wn * es)]
+        if st.inputs[0].needs_grad:
+            passes.append(("dgrad", xb + zb + wn * es))
+        passes.append(("wgrad", xb + zb + wn * 4))
+        row = {"layer": st.pname}
+        for name, nbytes in passes:
+            tf, tb = fl / peak * 1e3, nbytes / (hbm_tbs * 1e12) * 1e3
+            t_f, t_b, t_max = t_f + tf, t_b + tb, t_max + max(tf, tb)
+            row[name] = [round(tf, 4), round(tb, 4)]
+        layers.append(row)
+    return {"t_flops_ms": round(t_f, 3), "t_bytes_ms": round(t_b, 3), "bound_ms": round(t_max, 3), "layers": layers}
+
+
 def secondary_configs(torch, device, image, steps=10, warmup=3):
     """BASELINE configs[2] and configs[4] (one GPU each), a few seconds in all, inside the same JSON line so that a driver-timed
     figure exists for them: LightCNN-9 256-d, 512 images, bf16, in-batch semi-hard mining (every image an anchor);
@@ -207,7 +247,12 @@ def secondary_configs(torch, device, image, steps=10, warmup=3):
             loss = tr.step(xs[i % 2], None)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        res[key] = {"triplets_per_s": round(batch / dt, 1), "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+        bound = step_bound(tr.plan, PEAK_BF16_MFMA_TFLOPS)
+        res[key] = {"roofline": {"bound": "sum over layers and passes of max(t_flops, t_bytes) (SURVEY.md §8d): MFMA 2.5 PFLOP/s dense bf16 / HBM 8 TB/s",
+                                 "t_flops_ms": bound["t_flops_ms"], "t_bytes_ms": bound["t_bytes_ms"], "bound_ms": bound["bound_ms"],
+                                 "achieved_ms": round(dt * 1e3, 3), "frac": round(bound["bound_ms"] / (dt * 1e3), 4),
+                                 "governs": "mfma" if bound["t_flops_ms"] >= bound["t_bytes_ms"] else "hbm"},
+                    "triplets_per_s": round(batch / dt, 1), "images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                     "warmup": warmup, "dtype": "bf16 operands / activations, fp32 accumulate + master weights",
                     "step_mfma_roofline_frac": round(batch / dt * flop / (PEAK_BF16_MFMA_TFLOPS * 1e12), 4), "peak_tflops": PEAK_BF16_MFMA_TFLOPS,
                     "loss": round(float(loss.mean().item()), 6)}

@@ -71,6 +71,7 @@ SIGNATURES = {
     "efm_wino_mfm_make_u": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]),
     "efm_wino_mfm_fwd": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "efm_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "efm_rowpack_nchw": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "efm_crop_mirror_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_float, c_void_p]),
     "efm_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "efm_mfm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

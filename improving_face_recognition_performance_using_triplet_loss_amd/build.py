@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libefm_hip.so")
-SOURCES = ["efm_api.hip", "efm_conv.hip", "efm_winograd.hip", "efm_wino_wgrad.hip", "efm_elementwise.hip", "efm_head.hip", "efm_predict.hip"]
+SOURCES = ["efm_api.hip", "efm_conv.hip", "efm_winograd.hip", "efm_wino_wgrad.hip", "efm_convb_wgrad.hip", "efm_elementwise.hip", "efm_head.hip", "efm_predict.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-source extras: the SLP vectoriser packs the Winograd weight gradient's operand transforms into v_pk_*_f32, which is slower beside MFMAs
 EXTRA = {"efm_wino_wgrad.hip": ["-fno-slp-vectorize"]}

@@ -67,6 +67,12 @@ int wino_wgrad_finish(const efm_conv_desc* d, float* dw_packed, float* dbias, in
                       hipStream_t s);
 int wino_wgrad_info(const efm_conv_desc* d, char* name, size_t len, double* flops);
 
+// bf16 weight gradient in halo-tile form (efm_convb_wgrad.hip) behind efm_convb_bwd_weight: taken wherever it applies (EFM_WGRAD2=0: never).
+bool wgrad2_selected(const efm_conv_desc* d);
+int wgrad2_splits(const efm_conv_desc* d);
+int wgrad2_slabs(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* slabs, float* bias_part, hipStream_t s);
+int wgrad2_info(const efm_conv_desc* d, char* name, size_t len, double* flops);
+
 // Raw-buffer offsets are 32 bits and the kernels use byte offset 2^31 (EFM_OOB) as the "always out of range" address that the
 // buffer range check turns into zeros (padding taps, tail rows): every activation tensor a convolution kernel addresses must
 // therefore stay BELOW 2^31 bytes, or the sentinel would land inside the tensor and read data instead of zeros.

@@ -145,7 +145,8 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
     const unsigned k = (unsigned)(t * KS + kc4);
     const unsigned tap = __umulhi(k, p.magic_c);
     const int c = (int)(k - tap * (unsigned)p.cin_p);
-    const unsigned kh_ = __umulhi(tap, p.magic_kw), kw_ = tap - kh_ * (unsigned)p.kw;
+    // (kw == 1: ceil(2^32 / 1) does not fit the 32-bit multiplier — kx1 kernels, e.g. the row-packed first convolution)
+    const unsigned kh_ = (p.kw == 1) ? tap : __umulhi(tap, p.magic_kw), kw_ = tap - kh_ * (unsigned)p.kw;
     const bool tap_ok = (int)tap < taps;
     const int doff = ((int)kh_ * p.win + (int)kw_) * p.cin_p + c;
     if (DMA) {
@@ -239,6 +240,59 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
   }
 
   if (EPI == 0) {
+    if constexpr (BF) {
+      // ---- plain epilogue, bf16: a lane's result elements are 2 bytes in 16 different places of 4 rows — stored directly, a wave
+      // instruction writes four 32-byte slivers (M*N/64 store instructions per launch: measured, these narrow stores and not the
+      // matrix cores bound the short-K layers).  So the rows go through the wave's own LDS region [R rows][BN + 4] as fp32 (the
+      // staging buffers are dead: the K loop ended with a block barrier; a wave touches only its region) and come back as
+      // (row, 8 consecutive channels) per lane: bias added on the way in, residual (one 16-byte load) on the way out, ONE 16-byte
+      // store per lane — 8x fewer, 8x wider stores.
+      constexpr int R = (NT <= 8) ? 16 : 8;
+      constexpr int ES = BN + 4;
+      float* Es = smem + wave * (R * ES);
+      const int G = min(BN, p.cout_p - n0) >> 3;  // 8-channel groups of this block's columns that exist in y (cout_p % 8 == 0)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int h = 0; h < 16 / R; ++h) {
+          if (R == 16 || (fq >> 1) == h) {
+            const int rr = (R == 16) ? 4 * fq : 4 * (fq & 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int n = n0 + nt * 16 + fi;
+              const float bv = (p.bias && n < p.n_pad16) ? p.bias[n] : 0.f;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Es[(rr + r) * ES + nt * 16 + fi] = acc[mt][nt][r] + bv;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int row0 = m0 + wave * (MT * 16) + mt * 16 + h * R;
+          for (int it = lane; it < R * G; it += 64) {
+            const int row = it / G, g = it - row * G;
+            const long m = row0 + row;
+            if (m < p.M) {
+              const float* e = Es + row * ES + g * 8;
+              const f32x4 v0 = *reinterpret_cast<const f32x4*>(e), v1 = *reinterpret_cast<const f32x4*>(e + 4);
+              float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+              const long off = m * p.cout_p + n0 + g * 8;
+              if (p.res) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(p.res) + off);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
+              }
+              bf16x8 o;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) o[k] = (__bf16)v[k];
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + off) = o;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // the next pass overwrites the region
+        }
+      }
+      return;
+    }
     // ---- plain epilogue: D[row = 4*fq + r][col = fi] per 16x16 tile; + bias (+ residual)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -313,6 +367,59 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int row0 = m0 + wave * (MT * 16) + mt * 16 + h * R;  // first result row of this pass
+      bool done_vec = false;
+      if constexpr (BF) {
+        // ---- bf16, slice widths on the 8-channel grid (every MFM layer of LightCNN-9 / the deeper CNN): lane = (window | pixel,
+        // group of 8 channels): the slices' values come from the region as 16-byte reads, z leaves as ONE 16-byte store and the
+        // route bytes as ONE 8-byte store per lane and slice half.  Same comparisons in the same order as the scalar path below
+        // (same values, same route bytes) — what changes is 4-8x fewer, 8x wider store instructions: the narrow stores, not the
+        // matrix cores, bounded the short-K layers (conv1, the 1x1 convolutions).
+        if (!zf32 && ways == 2 && (cnb & 7) == 0 && (cb & 7) == 0 && (cs & 7) == 0) {
+          // (two-slice MFM only: the three-slice form would keep twice the state live next to the accumulators and spill.
+          //  4 channels per lane: 8 per lane left most of a wave idle on the 8-row passes of the wide layers — 2 windows x 12 groups
+          //  = 24 of 64 lanes — and cost the kernel a resident block in registers; stores are 8 bytes of z + 4 route bytes per lane,
+          //  the lanes of a window contiguous.)
+          done_vec = true;
+          const int G = cnb >> 2;
+          __bf16* zb = reinterpret_cast<__bf16*>(p.y);
+          const int items = (p.pool ? R / 4 : R) * G;
+          for (int it = lane; it < items; it += 64) {
+            const int u = it / G, g = it - u * G;              // u = window (pooled) or row of this pass
+            const int m = row0 + (p.pool ? 4 * u : u);
+            if (m >= p.M) continue;
+            const float* e = Es + (p.pool ? 4 * u : u) * ES + g * 4;
+            f32x4 bmax;
+            unsigned rt4 = 0u;                                  // route bytes of the 4 channels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j > 0 && !p.pool) break;
+              const f32x4 a0 = *reinterpret_cast<const f32x4*>(e + j * ES), b0 = *reinterpret_cast<const f32x4*>(e + j * ES + cnb);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const unsigned rt = (unsigned)(j * 4) + ((a0[k] >= b0[k]) ? 0u : 1u);   // tie -> slice 0 (MXNet: lhs wins)
+                const float vmax = fmaxf(a0[k], b0[k]);
+                const bool take = (j == 0) || vmax > bmax[k];                           // first maximum of the window wins
+                bmax[k] = take ? vmax : bmax[k];
+                rt4 = take ? ((rt4 & ~(0xffu << (8 * k))) | (rt << (8 * k))) : rt4;
+              }
+            }
+            const long q = p.pool ? (long)(m >> 2) : (long)m;
+            const long o = q * cpo + cb + g * 4;
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 zv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zv[k] = (__bf16)bmax[k];
+            *reinterpret_cast<bf16x4*>(zb + o) = zv;
+            *reinterpret_cast<unsigned*>(p.route + o) = rt4;
+          }
+          // co = cs or 2*cs is a multiple of 8 here, so cpo == co: no pad channels to clear
+        }
+      }
+      if (done_vec) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
       if (p.pool) {
 #pragma unroll
         for (int wnd = 0; wnd < R / 4; ++wnd) {
@@ -384,7 +491,7 @@ template <typename T, int MT, int NT, bool DMA, int EPI>
 __global__ void __launch_bounds__(256, EFM_FWD_OCC) conv_fwd_k(const ConvP p) {
   // K-loop double buffer, re-used by the fused epilogue as 4 per-wave transposition regions of R rows x (BN + 4)
   __shared__ __attribute__((aligned(16))) float smem[cmax(2 * (MT * 64 + NT * 16) * 16,
-                                                            EPI ? 4 * ((NT <= 8) ? 16 : 8) * (NT * 16 + 4) : 0)];
+                                                            (EPI || sizeof(T) == 2) ? 4 * ((NT <= 8) ? 16 : 8) * (NT * 16 + 4) : 0)];
   conv_fwd_body<T, MT, NT, DMA, EPI>(p, smem);
 }
 
@@ -996,6 +1103,14 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_bf16_k(const float* __restri
 
 // fp32 packed master weight -> bf16 forward weight wb[n][tap*cin_p8 + ci] and bf16 data-gradient weight
 // wdb[ci][flip(tap)*cout_p8 + co]; one thread per destination element of either matrix.
+// A fully connected layer (kernel = whole map, one output pixel: FullyConnected(513) / Dense, ref: efm_symbol.py:94) has a data
+// gradient that is a plain GEMM dx[b][(tap, ci)] = sum_co dy[b][co] w[co][(tap, ci)]; run as a "full correlation" it would contract
+// over taps x cout with all but one tap of every output pixel out of range (49x the work for a 7x7 map).  For such layers the
+// data-gradient weight is the transpose wdb[(tap, ci)][co] and the layer runs as a 1x1 convolution cout -> taps*cin on a 1x1 map.
+__host__ __device__ __forceinline__ bool fc_shaped(const efm_conv_desc& d) {
+  return d.hout == 1 && d.wout == 1 && d.pad_h == 0 && d.pad_w == 0 && d.kh == d.hin && d.kw == d.win && d.kh * d.kw > 1;
+}
+
 __global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restrict__ w32, __bf16* __restrict__ wb,
                                                            __bf16* __restrict__ wdb, efm_conv_desc d, long nf, long nd) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1007,6 +1122,14 @@ __global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restri
     float v = 0.f;
     if (n < d.cout && tap < taps && ci < d.cin) v = w32[(long)n * d.k_pad + tap * d.cin_p + ci];
     wb[i] = (__bf16)v;
+  } else if (i < nf + nd && wdb != nullptr && fc_shaped(d)) {
+    const long e = i - nf;
+    const int kp = pad32(cout8);
+    const int n = (int)(e / kp), co = (int)(e - (long)n * kp);
+    const int tap = n / cin8, ci = n - tap * cin8;
+    float v = 0.f;
+    if (tap < taps && ci < d.cin && co < d.cout) v = w32[(long)co * d.k_pad + tap * d.cin_p + ci];
+    wdb[e] = (__bf16)v;
   } else if (i < nf + nd && wdb != nullptr) {
     const long e = i - nf;
     const int kp = pad32(taps * cout8);
@@ -1542,8 +1665,23 @@ int efm_conv_kernel_info(const efm_conv_desc* d, int pass, int ways, int pool, c
 
 // ---------------------------------------------------------------------------------------- bf16 path
 size_t efm_convb_weight_elems(const efm_conv_desc* d) { return (size_t)d->n_pad16 * pad32(d->kh * d->kw * pad8(d->cin)); }
-size_t efm_convb_dgrad_weight_elems(const efm_conv_desc* d) { return (size_t)d->dn_pad16 * pad32(d->kh * d->kw * pad8(d->cout)); }
-size_t efm_convb_wgrad_workspace_bytes(const efm_conv_desc* d) { return plan_wgradb(d).ws_floats * sizeof(float); }
+size_t efm_convb_dgrad_weight_elems(const efm_conv_desc* d) {
+  if (fc_shaped(*d)) return (size_t)efm_pad16(d->kh * d->kw * pad8(d->cin)) * pad32(pad8(d->cout));  // transposed weight of the GEMM form
+  return (size_t)d->dn_pad16 * pad32(d->kh * d->kw * pad8(d->cout));
+}
+// slabs | second-level slabs (more than 32 slabs reduce in two levels) | bias partials (both levels) of a bf16 weight gradient with
+// `splits` slabs and `chunks` bias partials
+static size_t wgradb_ws_floats(const efm_conv_desc* d, int kb_pad, int splits, int chunks) {
+  const size_t slab = (size_t)d->n_pad16 * kb_pad;
+  return slab * splits + (splits > 32 ? 32 * slab : 0) + (size_t)(chunks + (chunks + 31) / 32) * d->n_pad16;
+}
+size_t efm_convb_wgrad_workspace_bytes(const efm_conv_desc* d) {
+  if (efm::wgrad2_selected(d)) {
+    const int sp = efm::wgrad2_splits(d);
+    return wgradb_ws_floats(d, pad32(d->kh * d->kw * pad8(d->cin)), sp, sp) * sizeof(float);
+  }
+  return plan_wgradb(d).ws_floats * sizeof(float);
+}
 
 int efm_nchw_to_nhwc_bf16(const float* x, uint16_t* y, int batch, int c, int h, int w, void* stream) {
   EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0, "nchw_to_nhwc_bf16: bad argument");
@@ -1573,6 +1711,11 @@ int efm_convb_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb,
 int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_t* wdb, const uint16_t* add, uint16_t* dx, void* stream) {
   EFM_REQUIRE(d && dy && wdb && dx, "convb_bwd_data: null argument");
   EFM_REQUIRE_RANGE(d, 2, "convb_bwd_data");
+  if (fc_shaped(*d)) {  // fully connected: dx[b][(tap, ci)] = dy[b][:] . wdb[(tap, ci)][:] — a 1x1 convolution cout -> taps*cin on a 1x1 map
+    const int nrow = d->kh * d->kw * pad8(d->cin);
+    return run_fwd<__bf16>(dy, wdb, nullptr, add, dx, d->batch, 1, 1, pad8(d->cout), 1, 1, nrow, 1, 1, 0, 0, efm_pad16(nrow), pad32(pad8(d->cout)),
+                           d->tune_dgrad, (hipStream_t)stream);
+  }
   return run_fwd<__bf16>(dy, wdb, nullptr, add, dx, d->batch, d->hout, d->wout, pad8(d->cout), d->hin, d->win, pad8(d->cin), d->kh, d->kw,
                          d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, pad32(d->kh * d->kw * pad8(d->cout)), d->tune_dgrad,
                          (hipStream_t)stream);
@@ -1742,33 +1885,49 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
                          void* workspace, size_t workspace_bytes, void* stream) {
   EFM_REQUIRE(d && x && dy && dw_packed, "convb_bwd_weight: null argument");
   EFM_REQUIRE_RANGE(d, 2, "convb_bwd_weight");
-  const WgradBPlan pl = plan_wgradb(d);
+  hipStream_t s = (hipStream_t)stream;
+  const bool halo = efm::wgrad2_selected(d);   // the halo-tile form (efm_convb_wgrad.hip) wherever it applies
+  WgradBPlan pl;
+  if (halo) {
+    pl.splits = efm::wgrad2_splits(d);
+    pl.bias_chunks = pl.splits;
+    pl.kb_pad = pad32(d->kh * d->kw * pad8(d->cin));
+    pl.slab_floats = (size_t)pl.splits * d->n_pad16 * pl.kb_pad;
+    pl.lvl2_floats = pl.splits > 32 ? (size_t)32 * d->n_pad16 * pl.kb_pad : 0;
+    pl.ws_floats = wgradb_ws_floats(d, pl.kb_pad, pl.splits, pl.bias_chunks);
+  } else {
+    pl = plan_wgradb(d);
+  }
   if (!workspace || workspace_bytes < pl.ws_floats * sizeof(float)) {
     efm::set_error("convb_bwd_weight: workspace %zu B < required %zu B", workspace_bytes, pl.ws_floats * sizeof(float));
     return EFM_E_WORKSPACE;
   }
-  hipStream_t s = (hipStream_t)stream;
-  WgradBP p;
-  p.x = reinterpret_cast<const __bf16*>(x); p.dy = reinterpret_cast<const __bf16*>(dy); p.ws = (float*)workspace;
-  p.M = d->batch * d->hout * d->wout;
-  p.hin = d->hin; p.win = d->win; p.cin_p = pad8(d->cin);
-  p.hout = d->hout; p.wout = d->wout; p.cout_p = pad8(d->cout);
-  p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
-  p.n_pad16 = d->n_pad16; p.kb_pad = pl.kb_pad;
-  p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
-  p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * p.cin_p * 2);
-  p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * p.cout_p * 2);
   float* lvl2 = (float*)workspace + pl.slab_floats;
   float* bpart = lvl2 + pl.lvl2_floats;
   float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
-  p.bias_part = dbias ? bpart : nullptr;
-
-  p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
-  dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
-  int rc = (pl.KPW == 2) ? launch_wgradb_nt<2>(pl.NTW, grid, s, p) : launch_wgradb_nt<1>(pl.NTW, grid, s, p);
-  if (rc != EFM_OK) return rc;
-  rc = efm::check_launch("convb_wgrad");
-  if (rc != EFM_OK) return rc;
+  int rc;
+  if (halo) {
+    rc = efm::wgrad2_slabs(d, x, dy, (float*)workspace, dbias ? bpart : nullptr, s);
+    if (rc != EFM_OK) return rc;
+  } else {
+    WgradBP p;
+    p.x = reinterpret_cast<const __bf16*>(x); p.dy = reinterpret_cast<const __bf16*>(dy); p.ws = (float*)workspace;
+    p.M = d->batch * d->hout * d->wout;
+    p.hin = d->hin; p.win = d->win; p.cin_p = pad8(d->cin);
+    p.hout = d->hout; p.wout = d->wout; p.cout_p = pad8(d->cout);
+    p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+    p.n_pad16 = d->n_pad16; p.kb_pad = pl.kb_pad;
+    p.kblocks = pl.kblocks; p.nblocks = pl.nblocks; p.splits = pl.splits; p.m_per_split = pl.m_per_split;
+    p.x_bytes = (unsigned)((size_t)d->batch * d->hin * d->win * p.cin_p * 2);
+    p.y_bytes = (unsigned)((size_t)d->batch * d->hout * d->wout * p.cout_p * 2);
+    p.bias_part = dbias ? bpart : nullptr;
+    p.mma_blocks = pl.kblocks * pl.nblocks * pl.splits;
+    dim3 grid((unsigned)(p.mma_blocks + (dbias ? pl.bias_chunks : 0)));
+    rc = (pl.KPW == 2) ? launch_wgradb_nt<2>(pl.NTW, grid, s, p) : launch_wgradb_nt<1>(pl.NTW, grid, s, p);
+    if (rc != EFM_OK) return rc;
+    rc = efm::check_launch("convb_wgrad");
+    if (rc != EFM_OK) return rc;
+  }
   const long total = (long)d->n_pad16 * d->k_pad;
   const float* slabs = (const float*)workspace;
   int nslabs = pl.splits;

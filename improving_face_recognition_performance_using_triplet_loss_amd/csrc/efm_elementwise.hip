@@ -28,6 +28,37 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_k(const float* __restrict__ 
   *reinterpret_cast<f32x4*>(y + pix * cp + g * 4) = v;
 }
 
+// ---- NCHW -> row-packed NHWC: y[b][h][w][j*c + ch] = x[b][ch][h][w + j - pad_w] (zero outside the row), j < kw.
+// The kw taps of one kernel row become CHANNELS of the pixel, so a kh x kw convolution on c channels turns into a kh x 1
+// convolution on kw*c channels with the same weights re-indexed: the first layer's K = kh*kw*c then packs densely
+// (5x5 on 3 channels: 5 * pad4(15) = 80 instead of 25 * pad4(3) = 100 -> 112 in fp32; 96 instead of 224 in bf16).
+// One thread per (pixel, group of G channels); T = float (G = 4, 16-byte store) or __bf16 (G = 8, 16-byte store).
+template <typename T, int G>
+__global__ void __launch_bounds__(256) rowpack_nchw_k(const float* __restrict__ x, T* __restrict__ y, unsigned total, efm::FastDiv ngd,
+                                                      efm::FastDiv wd, efm::FastDiv cd, int c, int hw, int w, int kw, int pad_w, int cp) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned pix = efm::div(i, ngd);
+  const int g = (int)(i - pix * ngd.d);
+  const unsigned row = efm::div(pix, wd);            // (b * h + hh)
+  const int ww = (int)(pix - row * wd.d);
+  const unsigned b = row / (unsigned)(hw / w), hh = row - b * (unsigned)(hw / w);
+  T v[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const unsigned s = (unsigned)(g * G + k);
+    const unsigned j = efm::div(s, cd);
+    const int ch = (int)(s - j * cd.d);
+    const int wi = ww + (int)j - pad_w;
+    float f = 0.f;
+    if ((int)j < kw && (unsigned)wi < (unsigned)w) f = x[((long)b * c + ch) * hw + (long)hh * w + wi];
+    v[k] = (T)f;
+  }
+  T* dst = y + (long)pix * cp + g * G;
+#pragma unroll
+  for (int k = 0; k < G; ++k) dst[k] = v[k];   // G consecutive elements of one thread: merged into one 16-byte store
+}
+
 __global__ void __launch_bounds__(256) nhwc_to_nchw_k(const float* __restrict__ x, float* __restrict__ y,
                                                       long total, int c, int hw, int cp) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -234,6 +265,21 @@ int efm_nchw_to_nhwc(const float* x, float* y, int batch, int c, int h, int w, v
   hipLaunchKernelGGL(nchw_to_nhwc_k, dim3((unsigned)efm::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                      pixels, c, h * w, cp);
   return efm::check_launch("nchw_to_nhwc");
+}
+
+int efm_rowpack_nchw(const float* x, void* y, int batch, int c, int h, int w, int kw, int pad_w, int bf16, void* stream) {
+  EFM_REQUIRE(x && y && batch > 0 && c > 0 && h > 0 && w > 0 && kw > 0 && pad_w >= 0, "rowpack_nchw: bad argument");
+  const int cr = kw * c, cp = bf16 ? ((cr + 7) & ~7) : efm_pad4(cr), G = bf16 ? 8 : 4;
+  const long pixels = (long)batch * h * w, n = pixels * (cp / G);
+  EFM_REQUIRE(n < 0x100000000L && pixels * cp * (bf16 ? 2 : 4) < 0x80000000L, "rowpack_nchw: output reaches 2^31 bytes (split the batch)");
+  const dim3 grid((unsigned)efm::cdiv(n, 256));
+  if (bf16)
+    hipLaunchKernelGGL((rowpack_nchw_k<__bf16, 8>), grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<__bf16*>(y), (unsigned)n,
+                       efm::fastdiv(cp / 8), efm::fastdiv(w), efm::fastdiv(c), c, h * w, w, kw, pad_w, cp);
+  else
+    hipLaunchKernelGGL((rowpack_nchw_k<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<float*>(y), (unsigned)n,
+                       efm::fastdiv(cp / 4), efm::fastdiv(w), efm::fastdiv(c), c, h * w, w, kw, pad_w, cp);
+  return efm::check_launch("rowpack_nchw");
 }
 
 int efm_nhwc_to_nchw(const float* x, float* y, int batch, int c, int h, int w, void* stream) {

@@ -84,6 +84,9 @@ struct Op {
 struct Predictor {
   int batch = 0, c = 0, h = 0, w = 0, feat = 342;
   float *x_nchw = nullptr, *x_nhwc = nullptr, *feat_dev = nullptr;
+  // first convolution on a row-packed input (efm_rowpack_nchw), exactly as the training plan runs it: x_nhwc then holds
+  // [b][h][w][pad4(kw*c)] and rowpack_kw / rowpack_pad say how it is filled (0 = plain NHWC conversion)
+  int rowpack_kw = 0, rowpack_pad = 0;
   std::vector<Op> ops;
   std::vector<void*> owned;
   uint32_t out_shape[2] = {0, 0};
@@ -131,17 +134,36 @@ bool add_conv(Predictor& P, const std::map<std::string, Blob>& params, const std
   op.kind = mode ? 1 : 0;
   int kh = k, kw = k;
   if (k == 0) { kh = cur.h; kw = cur.w; }  // fully connected = 'valid' conv over the whole map
-  if (efm_conv_desc_init(&op.d, P.batch, cur.h, cur.w, cur.c, cout, kh, kw, pad, pad) != EFM_OK) return false;
+  // the FIRST convolution (its input is the network input) runs on the row-packed image like the training plan's (plan.py: rowpack):
+  // kh x 1 on kw*c channels, weights re-indexed w'[n][j*c + ci][kh] = w[n][ci][kh][j] — same kernels, same bits as the trainer
+  static const bool rowpack_on = [] { const char* e = getenv("EFM_ROWPACK"); return !(e && atoi(e) == 0); }();  // as plan.py
+  const bool rowpack = rowpack_on && cur.p == P.x_nhwc && k > 1 && 2 * pad == k - 1 && k * cur.c <= 16 && P.rowpack_kw == 0;
   const size_t expect = (size_t)cout * cur.c * kh * kw;
   if (wi->second.data.size() != expect || (int)bi->second.data.size() != cout) {
     efm::set_error("pred_create: %s has %zu weights, expected %zu", name.c_str(), wi->second.data.size(), expect);
+    return false;
+  }
+  std::vector<float> w_row;
+  const float* w_host = wi->second.data.data();
+  if (rowpack) {
+    w_row.resize(expect);
+    for (int n = 0; n < cout; ++n)
+      for (int ci = 0; ci < cur.c; ++ci)
+        for (int a = 0; a < kh; ++a)
+          for (int j = 0; j < kw; ++j)
+            w_row[((size_t)n * (kw * cur.c) + (j * cur.c + ci)) * kh + a] = w_host[(((size_t)n * cur.c + ci) * kh + a) * kw + j];
+    w_host = w_row.data();
+    P.rowpack_kw = kw;
+    P.rowpack_pad = pad;
+    if (efm_conv_desc_init(&op.d, P.batch, cur.h, cur.w, kw * cur.c, cout, kh, 1, pad, 0) != EFM_OK) return false;
+  } else if (efm_conv_desc_init(&op.d, P.batch, cur.h, cur.w, cur.c, cout, kh, kw, pad, pad) != EFM_OK) {
     return false;
   }
   float* w_oihw = P.alloc<float>(expect);
   op.w = P.alloc<float>(efm_conv_weight_elems(&op.d));
   op.bias = P.alloc<float>(op.d.n_pad16);
   if (!w_oihw || !op.w || !op.bias) return false;
-  if (hipMemcpy(w_oihw, wi->second.data.data(), expect * 4, hipMemcpyHostToDevice) != hipSuccess ||
+  if (hipMemcpy(w_oihw, w_host, expect * 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(op.bias, 0, op.d.n_pad16 * 4) != hipSuccess ||
       hipMemcpy(op.bias, bi->second.data.data(), cout * 4, hipMemcpyHostToDevice) != hipSuccess) {
     efm::set_error("pred_create: uploading %s failed", name.c_str());
@@ -239,7 +261,7 @@ int efm_pred_create(const char* symbol_json, const void* param_bytes, int param_
     return EFM_E_LAUNCH;
   }
   P->x_nchw = P->alloc<float>((size_t)P->batch * P->c * P->h * P->w);
-  P->x_nhwc = P->alloc<float>((size_t)P->batch * P->h * P->w * efm_pad4(P->c));
+  P->x_nhwc = P->alloc<float>((size_t)P->batch * P->h * P->w * (efm_pad4(P->c) > 16 ? efm_pad4(P->c) : 16));  // plain NHWC (pad4(c)) or the row-packed image (<= 16 channels)
   if (!P->x_nchw || !P->x_nhwc || !build_efm29(*P, params) || hipStreamSynchronize(P->stream) != hipSuccess) {
     delete P;
     return EFM_E_INVALID;
@@ -257,7 +279,8 @@ int efm_pred_set_input(void* handle, const char* key, const float* data, uint32_
 }
 
 static int pred_enqueue(Predictor* P) {
-  int rc = efm_nchw_to_nhwc(P->x_nchw, P->x_nhwc, P->batch, P->c, P->h, P->w, P->stream);
+  int rc = P->rowpack_kw ? efm_rowpack_nchw(P->x_nchw, P->x_nhwc, P->batch, P->c, P->h, P->w, P->rowpack_kw, P->rowpack_pad, 0, P->stream)
+                         : efm_nchw_to_nhwc(P->x_nchw, P->x_nhwc, P->batch, P->c, P->h, P->w, P->stream);
   for (size_t i = 0; rc == EFM_OK && i < P->ops.size(); ++i) {
     const Op& op = P->ops[i];
     if (op.kind == 0)

@@ -174,6 +174,16 @@ def nchw_to_nhwc(x, out=None):
     return out
 
 
+def rowpack_nchw(x, kw, pad_w, bf16=False):
+    """NCHW fp32 -> row-packed NHWC (efm_rowpack_nchw): (B, H, W, pad(kw*C)), fp32 (channel stride pad4) or bf16 (pad8)."""
+    _need_dev(x)
+    b, c, h, w = x.shape
+    cp = (kw * c + 7) & ~7 if bf16 else pad4(kw * c)
+    out = torch.empty((b, h, w, cp), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device)
+    check(_lib.load().efm_rowpack_nchw(_p(x), _p(out), b, c, h, w, kw, pad_w, 1 if bf16 else 0, _stream()), "efm_rowpack_nchw")
+    return out
+
+
 def crop_mirror_u8(src, crop, h, w, scale=1.0):
     """ImageRecordIter's crop / mirror / scale on the device: src uint8 (B, IH, IW, C) device tensor, crop int32 (B, 3) = (y0, x0,
     mirror) device tensor -> fp32 NCHW (B, C, h, w)."""

@@ -37,11 +37,27 @@ def _shared_stream(device, kind):
 
 
 class ParamSpec:
-    __slots__ = ("name", "kind", "offset", "numel", "desc", "mx_shape", "step")
+    __slots__ = ("name", "kind", "offset", "numel", "desc", "mx_shape", "step", "rowpack")
 
-    def __init__(self, name, kind, offset, numel, desc, mx_shape, step):
+    def __init__(self, name, kind, offset, numel, desc, mx_shape, step, rowpack=False):
         self.name, self.kind, self.offset, self.numel = name, kind, offset, numel
         self.desc, self.mx_shape, self.step = desc, mx_shape, step
+        # the first convolution on a row-packed input: `desc` is the kh x 1 convolution on kw*cin channels, the packed weight is
+        # w'[n][(j, ci)][kh] = w[n][ci][kh][j]; mx_shape stays MXNet's (cout, cin, kh, kw) and load / export / init re-index
+        self.rowpack = rowpack
+
+    def to_packed_order(self, a):
+        """MXNet (cout, cin, kh, kw) -> the (cout, cin', kh', kw') array `desc` packs."""
+        if not self.rowpack:
+            return a
+        cout, cin, kh, kw = self.mx_shape
+        return a.permute(0, 3, 1, 2).reshape(cout, kw * cin, kh, 1).contiguous()
+
+    def from_packed_order(self, w):
+        if not self.rowpack:
+            return w
+        cout, cin, kh, kw = self.mx_shape
+        return w.reshape(cout, kw, cin, kh).permute(0, 2, 3, 1).contiguous()
 
 
 class Step:
@@ -76,6 +92,7 @@ class Plan:
         self.input_shape = tuple(int(v) for v in input_shape)
         self.steps = []
         self.params = collections.OrderedDict()
+        self.rowpack = os.environ.get("EFM_ROWPACK", "1") != "0"
         self._lower(outputs)
         self.fuse = (os.environ.get("EFM_FUSE", "1") != "0") if fuse is None else bool(fuse)
         self.fused = 0
@@ -119,7 +136,20 @@ class Plan:
                     (kh, kw), (ph, pw), cout = n.attrs["kernel"], n.attrs["pad"], n.attrs["num_filter"]
                 else:
                     (kh, kw), (ph, pw), cout = (h, w), (0, 0), n.attrs["num_hidden"]
-                d = ops.conv_desc(b, h, w, c, cout, kh, kw, ph, pw)
+                rowpack = False
+                if (self.rowpack and n.op == "conv" and src.op == "input" and kw > 1 and 2 * pw == kw - 1 and kw * c <= 16
+                        and n.name + "_weight" not in self.params):
+                    # FIRST convolution (5x5 on 3 / 1 channels, ref: efm_symbol.py:84, lightcnn.py:82): the kw taps of a kernel row become
+                    # channels of a row-packed input (efm_rowpack_nchw), the layer runs as a kh x 1 convolution on kw*c channels and
+                    # K = kh*kw*c packs densely (80 instead of 112 in fp32, 96 instead of 224 in bf16)
+                    rp = Step("rowpack", n, [src], (kw * c, h, w))
+                    rp.kw, rp.pad_w = kw, pw
+                    rp.index = len(self.steps)
+                    self.steps.append(rp)
+                    src, rowpack = rp, True
+                    d = ops.conv_desc(b, h, w, kw * c, cout, kh, 1, ph, 0)
+                else:
+                    d = ops.conv_desc(b, h, w, c, cout, kh, kw, ph, pw)
                 st = Step("conv", n, [src], (cout, d.hout, d.wout))
                 st.desc, st.pname, st.no_bias = d, n.name, n.attrs["no_bias"]
                 wname = n.name + "_weight"
@@ -129,7 +159,7 @@ class Plan:
                         raise ValueError("shared parameter %s used with different shapes" % wname)
                 else:
                     nw = d.n_pad16 * d.k_pad
-                    self.params[wname] = ParamSpec(wname, "weight", offset, nw, d, (cout, c, kh, kw), st)
+                    self.params[wname] = ParamSpec(wname, "weight", offset, nw, d, (cout, c, kh, kw), st, rowpack)
                     offset += nw
                     if not st.no_bias:
                         self.params[n.name + "_bias"] = ParamSpec(n.name + "_bias", "bias", offset, d.n_pad16, d, (cout,), st)
@@ -172,6 +202,9 @@ class Plan:
             self.steps.append(st)
             step_of[n.id] = st
         self.outputs = [step_of[o.id] for o in outputs]
+        inputs = [s for s in self.steps if s.op == "input"]
+        self._input_raw = bool(inputs) and all(u.op == "rowpack" for u in self.steps for i in u.inputs if i.op == "input") \
+            and not any(o.op == "input" for o in self.outputs)
         self.num_flat = offset
         self._use_count = dict(use_count)
         # gradient need: everything downstream of a parameterised step; the raw input needs none
@@ -310,7 +343,7 @@ class Plan:
                 raise KeyError("missing parameter %s" % name)
             a = torch.as_tensor(np.asarray(params[name]), dtype=torch.float32).to(self.device)
             if ps.kind == "weight":
-                a = a.reshape(ps.mx_shape).contiguous()
+                a = ps.to_packed_order(a.reshape(ps.mx_shape).contiguous())
                 ops.conv_pack_weights_into(ps.desc, a, v[name])
             else:
                 v[name].zero_()
@@ -322,7 +355,7 @@ class Plan:
         out = collections.OrderedDict()
         for name, ps in self.params.items():
             if ps.kind == "weight":
-                w = ops.conv_unpack_weights(ps.desc, v[name])
+                w = ps.from_packed_order(ops.conv_unpack_weights(ps.desc, v[name]))
                 if ps.step.node.op == "fc":
                     w = w.reshape(ps.mx_shape[0], -1)
                 out[name] = w
@@ -345,7 +378,7 @@ class Plan:
             factor = {"avg": (fan_in + fan_out) / 2.0, "in": fan_in, "out": fan_out}[factor_type]
             scale = float(np.sqrt(magnitude / factor))
             w = (torch.rand(ps.mx_shape, generator=gen, device=self.device, dtype=torch.float32) * 2 - 1) * scale
-            ops.conv_pack_weights_into(ps.desc, w, v[name])
+            ops.conv_pack_weights_into(ps.desc, ps.to_packed_order(w), v[name])
 
     # ------------------------------------------------------------------------------ forward
     def forward(self, x, flat, train=True):
@@ -363,7 +396,12 @@ class Plan:
             self._make_wino_u(v, train)
         for st in self.steps:
             if st.op == "input":
-                acts[st.index] = ops.nchw_to_nhwc_bf16(x.contiguous()) if bf else ops.nchw_to_nhwc(x.contiguous())
+                if self._input_raw:   # only row-packing consumers: they read the NCHW tensor themselves
+                    acts[st.index] = x.contiguous()
+                else:
+                    acts[st.index] = ops.nchw_to_nhwc_bf16(x.contiguous()) if bf else ops.nchw_to_nhwc(x.contiguous())
+            elif st.op == "rowpack":
+                acts[st.index] = ops.rowpack_nchw(x.contiguous(), st.kw, st.pad_w, bf16=bf)
             elif st.op == "conv" and bf and not st.f32:
                 bias = None if st.no_bias else v[st.pname + "_bias"]
                 src = acts[st.inputs[0].index]
@@ -503,7 +541,7 @@ class Plan:
                         raise RuntimeError("backward() needs forward(train=True)")
                     prev = gr.pop(src.index, None)
                     gr[src.index] = ops.wino_bwd_data(d, dy, st.u_dgrad, add=prev)
-                elif src.needs_grad or (src.op == "input" and need_input_grad):
+                elif src.needs_grad or (src.op in ("input", "rowpack") and need_input_grad):
                     wd = self._wd_scratch[: d.dn_pad16 * d.dk_pad]
                     ops.conv_make_dgrad_weights(d, v[wname], out=wd)
                     prev = gr.pop(src.index, None)
@@ -539,6 +577,8 @@ class Plan:
                 ops.check(ops._lib.load().efm_l2norm_bwd(ops._p(acts[st.index]), ops._p(aux[st.index]), ops._p(dy), ops._p(dx),
                                                          self.batch, c, cp, cp, cp, 0, ops._stream()), "efm_l2norm_bwd")
                 gr[src.index] = dx
+            elif st.op == "rowpack":
+                raise NotImplementedError("input gradient through the row-packed first convolution (build the plan with EFM_ROWPACK=0)")
             elif st.op == "input":
                 dx_input = dy
         if side is not None:

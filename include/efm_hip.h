@@ -173,6 +173,12 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
  * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).
  * ------------------------------------------------------------------------------------ */
 int efm_nchw_to_nhwc(const float* x_nchw, float* y_nhwc, int batch, int c, int h, int w, void* stream);
+/* Row-packed input of the FIRST convolution (the 5x5 on 3 / 1 channels, ref: efm_symbol.py:84 group(data, 0, 99, (5,5), ...),
+ * lightcnn.py:82 efm(0, 99, (5,5), ...)): y[b][h][w][j*c + ch] = x[b][ch][h][w + j - pad_w] (0 outside the row), j < kw, channel
+ * stride pad4(kw*c) floats (bf16 = 0) or pad8(kw*c) bf16 (bf16 = 1).  A kh x kw convolution on c channels equals the kh x 1
+ * convolution (pad (pad_h, 0)) of y with the weights re-indexed w'[n][j*c + ch][kh] = w[n][ch][kh][j]: MXNet's Convolution forms
+ * the same im2col columns internally; here K = kh*kw*c packs densely instead of padding every tap's 3 channels to 4 / 8. */
+int efm_rowpack_nchw(const float* x_nchw, void* y_rowpacked, int batch, int c, int h, int w, int kw, int pad_w, int bf16, void* stream);
 /* mx.io.ImageRecordIter's augmentation on the device (ref: train_efm.py:179-181: scale=1./255, rand_crop, rand_mirror): decoded uint8
  * images src[b][ih][iw][c] (HWC, as an image decoder leaves them) -> dst[b][c][h][w] fp32 = scale * crop(mirror?(src)).
  * crop[b] = (y0, x0, mirror 0/1), drawn by the caller (the host iterator); the window must fit: y0 + h <= ih, x0 + w <= iw. */

@@ -31,6 +31,13 @@ CASES = [
     (2, 6, 6, 96, 384, 3, 1),
     (2, 7, 7, 128, 256, 3, 1),
     (2, 5, 5, 66, 99, 3, 1),     # channel counts that are no multiple of 8
+    # the halo-tile weight gradient (efm_convb_wgrad.hip): maps that cross its 4 x 16 stage tiles raggedly, one / three tap groups,
+    # one / two n parts, both wave-tile shapes
+    (2, 21, 37, 48, 192, 3, 1),
+    (1, 14, 14, 192, 256, 3, 1),
+    (3, 5, 19, 96, 384, 3, 1),
+    (2, 13, 9, 128, 256, 1, 0),
+    (1, 30, 18, 16, 96, 3, 1),
 ]
 
 
@@ -58,6 +65,8 @@ def test_convb_fwd_dgrad_wgrad(case):
     dw, db = ops.convb_bwd_weight(d, xd, dyd)
     assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < 2e-5   # fp32 output: only summation order differs
     assert rel_err(db[:cout].cpu().numpy(), db_ref) < 2e-5
+    dw2, db2 = ops.convb_bwd_weight(d, xd, dyd)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed-order reductions: bitwise reproducible
     dwm = dw.clone()
     ops.conv_pack_weights_into(d, ops.conv_unpack_weights(d, dw), dwm)
     assert torch.equal(dwm, dw)  # pad rows / columns of the packed gradient are exactly zero
@@ -287,3 +296,17 @@ def test_bf16_full_size_properties(net, batch):
     tr.backward()
     assert torch.isfinite(loss).all() and torch.isfinite(tr.grad).all() and float(tr.grad.abs().max()) > 0
     print("bf16 %s full size B=%d: shard-sum rel err %.2e, mean loss %.4f" % (net, batch, e_sum, float(loss.mean())))
+
+
+def test_convb_wgrad_of_the_rowpacked_first_convolution():
+    """5 x 1 kernel, pad (2, 0), 15 -> 96 channels on a 16-channel row-packed input: the shape the first convolution's weight gradient
+    has in the bf16 plans (one tap group of 5 kernel rows in the halo-tile form)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w, cin, cout = 2, 11, 23, 15, 96
+    x, dy = bf(rand((b, cin, h, w), 1)), bf(rand((b, cout, h, w), 2))
+    d = ops.conv_desc(b, h, w, cin, cout, 5, 1, 2, 0)
+    dw, db = ops.convb_bwd_weight(d, to_nhwc_bf16(ops, x), to_nhwc_bf16(ops, dy))
+    xp = np.pad(x, ((0, 0), (0, 0), (2, 2), (0, 0)))
+    dw_ref = np.stack([np.einsum("bchw,bnhw->nc", xp[:, :, a:a + h, :], dy) for a in range(5)], axis=2)[..., None]
+    assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < 2e-5
+    assert rel_err(db[:cout].cpu().numpy(), dy.sum(axis=(0, 2, 3))) < 2e-5

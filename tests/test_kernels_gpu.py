@@ -293,3 +293,84 @@ def test_gallery_scores(ops):
     scores, vals, idx = ops.gallery_match(dev(q), dev(g), topk=3)
     assert rel_err(scores.cpu().numpy(), q @ g.T) < 1e-5
     assert idx[:, 0].tolist() == [17, 900]
+
+
+@pytest.mark.parametrize("case", [(2, 3, 9, 11, 5, 2), (3, 1, 8, 8, 5, 2), (1, 3, 7, 5, 3, 1), (2, 2, 6, 6, 7, 3)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_rowpack_nchw(ops, case, bf16):
+    """efm_rowpack_nchw: y[b][h][w][j*c + ch] = x[b][ch][h][w + j - pad] with zeros outside the row and in the pad channels —
+    bit-exact in fp32, the bf16 rounding of the same values in bf16 (the row-packed input of the first convolution,
+    ref: efm_symbol.py:84 / lightcnn.py:82: the im2col columns of one kernel row)."""
+    b, c, h, w, kw, pad = case
+    x = rand((b, c, h, w), 5).astype(np.float32)
+    got = ops.rowpack_nchw(dev(x), kw, pad, bf16=bf16)
+    cp = (kw * c + 7) // 8 * 8 if bf16 else (kw * c + 3) // 4 * 4
+    assert tuple(got.shape) == (b, h, w, cp)
+    ref = np.zeros((b, h, w, cp), np.float32)
+    for j in range(kw):
+        for ww in range(w):
+            wi = ww + j - pad
+            if 0 <= wi < w:
+                ref[:, :, ww, j * c:(j + 1) * c] = x[:, :, :, wi].transpose(0, 2, 1)
+    if bf16:
+        assert torch.equal(got.cpu(), torch.from_numpy(ref).to(torch.bfloat16))
+    else:
+        assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_rowpacked_first_convolution_equals_the_plain_plan(ops, monkeypatch):
+    """The first convolution as a kh x 1 convolution on the row-packed input (Plan, EFM_ROWPACK=1, the default) against the same
+    network with the plain 5x5 convolution (EFM_ROWPACK=0): same parameters in MXNet layout in and out, embeddings / loss / every
+    exported gradient equal to fp32 summation order (the products and their order in k are the same; only the zero pads between
+    them move)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import synth
+    from improving_face_recognition_performance_using_triplet_loss_amd.trainer import TripletTrainer
+    batch, image = 8, 48
+    x = synth.images(batch, 3, image, 21)
+    neg = synth.negative_indices(synth.parity_labels(batch, images_per_identity=2), 3).cuda()
+    demb = (synth.uniform01(batch * 128, 7).view(batch, 128) * 2 - 1).contiguous()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EFM_ROWPACK", mode)
+        tr = TripletTrainer(batch, image=image, seed=5)
+        ps = tr.plan.params["conv1_weight"]
+        assert ps.rowpack == (mode == "1") and tuple(ps.mx_shape) == (99, 3, 5, 5)
+        assert (ps.desc.kh, ps.desc.kw, ps.desc.cin) == ((5, 1, 15) if mode == "1" else (5, 5, 3))
+        loss = tr.forward_loss(x, neg).clone()
+        tr.backward(demb=demb)
+        res[mode] = (tr.plan.export_params(tr.flat), tr.last["emb"].clone(), loss, tr.plan.export_params(tr.grad))
+    p0, e0, l0, g0 = res["0"]
+    p1, e1, l1, g1 = res["1"]
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k                      # same Xavier draw, same MXNet-layout parameters
+    assert rel_err(e1.cpu().numpy(), e0.cpu().numpy()) < 1e-5 and rel_err(l1.cpu().numpy(), l0.cpu().numpy()) < 1e-5
+    # gradients: the conv1 outputs of the two plans differ in the last bit, which flips a few max / min / pool routes downstream
+    # (see test_winograd_gpu.py) — every gradient, conv1's included, sees those flips; a wrong re-indexing would be O(1)
+    worst = max(rel_err(g1[k].cpu().numpy(), g0[k].cpu().numpy()) for k in g0)
+    a, b = g1["conv1_weight"].double().flatten(), g0["conv1_weight"].double().flatten()
+    assert worst < 5e-2, worst
+    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.99999
+
+
+def test_kx1_convolution_kernels(ops):
+    """kh x 1 kernels (the shape of the row-packed first convolution) through the forward, fused-epilogue and weight-gradient
+    kernels against the fp64 oracle run on the equivalent full-size problem: 5x1, pad (2, 0), 15 -> 30 channels."""
+    b, h, w, cin, cout = 2, 9, 7, 15, 30
+    x, wt, bias = rand((b, cin, h, w), 1), rand((cout, cin, 5, 1), 2, 0.3), rand((cout,), 3)
+    d = ops.conv_desc(b, h, w, cin, cout, 5, 1, 2, 0)
+    assert (d.hout, d.wout) == (h, w)
+    wp = ops.conv_pack_weights(d, dev(wt))
+    bp = torch.zeros(d.n_pad16, device="cuda")
+    bp[:cout] = dev(bias)
+    y = ops.conv_fwd(d, to_nhwc(x), wp, bp)
+    xp = np.pad(x, ((0, 0), (0, 0), (2, 2), (0, 0)))
+    ref = np.zeros((b, cout, h, w))
+    for a in range(5):
+        ref += np.einsum("bchw,nc->bnhw", xp[:, :, a:a + h, :], wt[:, :, a, 0])
+    ref += bias[None, :, None, None]
+    assert rel_err(from_nhwc(y, cout), ref) < 2e-4
+    dy = rand((b, cout, h, w), 4)
+    dw, db = ops.conv_bwd_weight(d, to_nhwc(x), to_nhwc(dy))
+    dw_ref = np.stack([np.einsum("bchw,bnhw->nc", xp[:, :, a:a + h, :], dy) for a in range(5)], axis=2)[..., None]
+    assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < 2e-4
+    assert rel_err(db[:cout].cpu().numpy(), dy.sum(axis=(0, 2, 3))) < 2e-4

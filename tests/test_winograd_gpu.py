@@ -86,7 +86,9 @@ def test_plan_with_winograd_layers_matches_direct_plan(monkeypatch):
     # gradients go through max / min / pool routes, and a last-bit difference in a forward value flips some: any two correct fp32
     # implementations differ by ~6e-3 there (measured in test_e2e_gpu.py::test_112_step_vs_oracles); a wiring error would be O(1).
     # The kernels themselves are compared tightly above.
-    assert rel_err(out["winograd"][2].cpu().numpy(), out["direct"][2].cpu().numpy()) < 3e-2
+    gw, gd = out["winograd"][2].double(), out["direct"][2].double()
+    assert rel_err(gw.cpu().numpy(), gd.cpu().numpy()) < 6e-2
+    assert float((gw * gd).sum() / (gw.norm() * gd.norm())) > 0.9995
 
 
 def test_inference_forward_between_training_forward_and_backward(monkeypatch):

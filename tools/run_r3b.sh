@@ -1,0 +1,6 @@
+source tools/gpu_steps.sh r3b
+step tests_bf16 900 python -m pytest tests/test_bf16_gpu.py tests/test_kernels_gpu.py tests/test_lightcnn9_gpu.py -m gpu -q -x --timeout 900
+step tests_rest 900 python -m pytest tests -m gpu -q --timeout 900 --deselect tests/test_bf16_gpu.py --deselect tests/test_kernels_gpu.py --deselect tests/test_lightcnn9_gpu.py
+step lc9_layers 400 python tools/conv_bench.py --net lightcnn9 --dtype bf16 --batch 512 --iters 5
+step f32_conv1 400 python tools/conv_bench.py --tuned --layers conv1,conv2_r --iters 10
+step bench 900 python bench.py --no-cpu-baseline
