@@ -59,6 +59,9 @@ SIGNATURES = {
     "efm_convb_bwd_data": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 5),
     "efm_convb_mfm_pool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p]),
     "efm_convb_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "efm_convb_mfm_bwd_weight_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "efm_convb_mfm_bwd_weight": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                         c_void_p]),
     "efm_wino_supported": (c_int, [POINTER(ConvDesc)]),
     "efm_wino_u_elems": (c_size_t, [POINTER(ConvDesc), c_int]),
     "efm_wino_make_u": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p]),

@@ -70,7 +70,10 @@ int wino_wgrad_info(const efm_conv_desc* d, char* name, size_t len, double* flop
 // bf16 weight gradient in halo-tile form (efm_convb_wgrad.hip) behind efm_convb_bwd_weight: taken wherever it applies (EFM_WGRAD2=0: never).
 bool wgrad2_selected(const efm_conv_desc* d);
 int wgrad2_splits(const efm_conv_desc* d);
-int wgrad2_slabs(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* slabs, float* bias_part, hipStream_t s);
+int wgrad2_bias_chunks(const efm_conv_desc* d);
+bool wgrad2_expand_supported(const efm_conv_desc* d, int ways, int pool);
+int wgrad2_slabs(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, const void* dz, const unsigned char* route, float* slabs,
+                 float* bias_part, hipStream_t s);
 int wgrad2_info(const efm_conv_desc* d, char* name, size_t len, double* flops);
 
 // Raw-buffer offsets are 32 bits and the kernels use byte offset 2^31 (EFM_OOB) as the "always out of range" address that the

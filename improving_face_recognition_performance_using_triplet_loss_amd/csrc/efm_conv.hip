@@ -1338,6 +1338,45 @@ __global__ void __launch_bounds__(256) slab_reduce_remap_k(const float* __restri
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// The bf16 weight gradient's reduction as ONE launch: blocks [0, gx_w) sum the `nslabs` slabs (bf16 K layout, channel stride cin_p8)
+// into the fp32 packed gradient (channel stride cin_p4) — 64 outputs x 4 slab lanes per block, lane l takes slabs l, l+4, ... in two
+// chains, the lanes are added in index order —, blocks [gx_w, ...) sum the `chunks` bias partials (reduce_part).  Fixed order,
+// no atomics.  (Was: a first level over groups of slabs, the remapping second level, and two levels for the bias: 4 launches per
+// layer, 28 small launches per LightCNN-9 step on the weight-gradient stream.)
+__global__ void __launch_bounds__(256) wgradb_reduce_k(const float* __restrict__ ws, float* __restrict__ out, efm_conv_desc d, int kb_pad,
+                                                       int nslabs, const float* __restrict__ bpart, float* __restrict__ dbias, long n4b,
+                                                       int chunks, int accumulate, int gx_w) {
+  __shared__ __attribute__((aligned(16))) float red[256 * 4];
+  if ((int)blockIdx.x >= gx_w) {
+    reduce_part<16, 16>(bpart, dbias, n4b, chunks, accumulate, (int)blockIdx.x - gx_w, red);
+    return;
+  }
+  const int cx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + cx;
+  const long total = (long)d.n_pad16 * d.k_pad;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < total) {
+    const int n = (int)(i / d.k_pad), k = (int)(i - (long)n * d.k_pad);
+    const int tap = k / d.cin_p, ci = k - tap * d.cin_p;
+    if (tap < d.kh * d.kw) {
+      const float* src = ws + (long)n * kb_pad + tap * pad8(d.cin) + ci;
+      const long stride = (long)d.n_pad16 * kb_pad;
+      int sp = sl;
+      for (; sp + 4 < nslabs; sp += 8) {
+        s0 += src[sp * stride];
+        s1 += src[(sp + 4) * stride];
+      }
+      if (sp < nslabs) s0 += src[sp * stride];
+    }
+  }
+  red[sl * 64 + cx] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    const float t = ((red[cx] + red[64 + cx]) + red[128 + cx]) + red[192 + cx];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
 template <int KPW>
 int launch_wgradb_nt(int NTW, dim3 grid, hipStream_t s, const WgradBP& p) {
   switch (NTW) {
@@ -1677,8 +1716,7 @@ static size_t wgradb_ws_floats(const efm_conv_desc* d, int kb_pad, int splits, i
 }
 size_t efm_convb_wgrad_workspace_bytes(const efm_conv_desc* d) {
   if (efm::wgrad2_selected(d)) {
-    const int sp = efm::wgrad2_splits(d);
-    return wgradb_ws_floats(d, pad32(d->kh * d->kw * pad8(d->cin)), sp, sp) * sizeof(float);
+    return wgradb_ws_floats(d, pad32(d->kh * d->kw * pad8(d->cin)), efm::wgrad2_splits(d), efm::wgrad2_bias_chunks(d)) * sizeof(float);
   }
   return plan_wgradb(d).ws_floats * sizeof(float);
 }
@@ -1881,16 +1919,14 @@ int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f3
   return efm::check_launch("convb_mfm_pool_bwd");
 }
 
-int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
-                         void* workspace, size_t workspace_bytes, void* stream) {
-  EFM_REQUIRE(d && x && dy && dw_packed, "convb_bwd_weight: null argument");
-  EFM_REQUIRE_RANGE(d, 2, "convb_bwd_weight");
+static int convb_bwd_weight_impl(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, const void* dz, const unsigned char* route,
+                                 float* dw_packed, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool halo = efm::wgrad2_selected(d);   // the halo-tile form (efm_convb_wgrad.hip) wherever it applies
   WgradBPlan pl;
   if (halo) {
     pl.splits = efm::wgrad2_splits(d);
-    pl.bias_chunks = pl.splits;
+    pl.bias_chunks = efm::wgrad2_bias_chunks(d);
     pl.kb_pad = pad32(d->kh * d->kw * pad8(d->cin));
     pl.slab_floats = (size_t)pl.splits * d->n_pad16 * pl.kb_pad;
     pl.lvl2_floats = pl.splits > 32 ? (size_t)32 * d->n_pad16 * pl.kb_pad : 0;
@@ -1907,7 +1943,7 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
   float* bpart2 = bpart + (size_t)pl.bias_chunks * d->n_pad16;
   int rc;
   if (halo) {
-    rc = efm::wgrad2_slabs(d, x, dy, (float*)workspace, dbias ? bpart : nullptr, s);
+    rc = efm::wgrad2_slabs(d, x, dy, dz, route, (float*)workspace, dbias ? bpart : nullptr, s);
     if (rc != EFM_OK) return rc;
   } else {
     WgradBP p;
@@ -1929,29 +1965,30 @@ int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16
     if (rc != EFM_OK) return rc;
   }
   const long total = (long)d->n_pad16 * d->k_pad;
-  const float* slabs = (const float*)workspace;
-  int nslabs = pl.splits;
-  if (pl.splits > 32) {  // level 1: groups of slabs -> at most 32 partial slabs
-    const long n4 = (long)d->n_pad16 * pl.kb_pad / 4;
-    const int per_group = (pl.splits + 31) / 32;
-    nslabs = (pl.splits + per_group - 1) / per_group;
-    hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)efm::cdiv(n4, 64), nslabs), dim3(256), 0, s, slabs, lvl2, n4, n4, pl.splits, per_group, n4, 0);
-    slabs = lvl2;
-  }
-  hipLaunchKernelGGL(slab_reduce_remap_k, dim3((unsigned)efm::cdiv(total, 256)), dim3(256), 0, s, slabs, dw_packed, *d,
-                     pl.kb_pad, nslabs, accumulate);
-  rc = efm::check_launch("convb_wgrad_reduce");
-  if (rc != EFM_OK || !dbias) return rc;
-  const long b4 = d->n_pad16 / 4;
-  const unsigned gx = (unsigned)efm::cdiv(b4, 64);
-  if (pl.bias_chunks > 32) {
-    const int groups = (pl.bias_chunks + 31) / 32;
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, groups), dim3(256), 0, s, (const float*)bpart, bpart2, b4, b4, pl.bias_chunks, 32, b4, 0);
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)bpart2, dbias, b4, b4, groups, groups, b4, accumulate);
-  } else {
-    hipLaunchKernelGGL(slab_reduce_k, dim3(gx, 1), dim3(256), 0, s, (const float*)bpart, dbias, b4, b4, pl.bias_chunks, pl.bias_chunks, b4, accumulate);
-  }
-  return efm::check_launch("convb_bias_reduce");
+  (void)lvl2; (void)bpart2;
+  const int gx_w = (int)efm::cdiv(total, 64), gx_b = dbias ? (int)efm::cdiv((long)d->n_pad16 / 4, 16) : 0;
+  hipLaunchKernelGGL(wgradb_reduce_k, dim3((unsigned)(gx_w + gx_b)), dim3(256), 0, s, (const float*)workspace, dw_packed, *d, pl.kb_pad, pl.splits,
+                     (const float*)bpart, dbias, (long)d->n_pad16 / 4, pl.bias_chunks, accumulate, gx_w);
+  return efm::check_launch("convb_wgrad_reduce");
+}
+
+int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && dy && dw_packed, "convb_bwd_weight: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_bwd_weight");
+  return convb_bwd_weight_impl(d, x, dy, nullptr, nullptr, dw_packed, dbias, accumulate, workspace, workspace_bytes, stream);
+}
+
+int efm_convb_mfm_bwd_weight_supported(const efm_conv_desc* d, int ways, int pool) {
+  return d && efm::wgrad2_expand_supported(d, ways, pool) ? 1 : 0;
+}
+
+int efm_convb_mfm_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const unsigned char* route, const uint16_t* dz, int ways, int pool,
+                             float* dw_packed, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  EFM_REQUIRE(d && x && route && dz && dw_packed, "convb_mfm_bwd_weight: null argument");
+  EFM_REQUIRE_RANGE(d, 2, "convb_mfm_bwd_weight");
+  EFM_REQUIRE(efm::wgrad2_expand_supported(d, ways, pool), "convb_mfm_bwd_weight: layer / epilogue not supported (ask efm_convb_mfm_bwd_weight_supported)");
+  return convb_bwd_weight_impl(d, x, nullptr, dz, route, dw_packed, dbias, accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

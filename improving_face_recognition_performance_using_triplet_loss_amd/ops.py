@@ -479,6 +479,25 @@ def convb_bwd_weight(d, x, dy, dw=None, dbias=None, want_bias=True, accumulate=F
     return dw, (dbias if want_bias else None)
 
 
+def convb_mfm_bwd_weight_supported(d, ways, pool):
+    return bool(_lib.load().efm_convb_mfm_bwd_weight_supported(ctypes.byref(d), int(ways), int(bool(pool))))
+
+
+def convb_mfm_bwd_weight(d, x, route, dz, ways, pool, dw=None, dbias=None, want_bias=True, accumulate=False):
+    """Weight (+ bias) gradient of a conv -> MFM2 -> 2x2 pooling layer straight from dz and the route bytes: the conv-output gradient is
+    formed in LDS, never in HBM (efm_convb_mfm_bwd_weight; replaces convb_mfm_pool_bwd + convb_bwd_weight where the input needs no gradient)."""
+    _need_dev(_bf(x), _bf(dz), route, dw, dbias)
+    if dw is None:
+        dw = torch.empty(conv_weight_shape(d), dtype=torch.float32, device=x.device)
+    if dbias is None and want_bias:
+        dbias = torch.empty((d.n_pad16,), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws = workspace(lib.efm_convb_wgrad_workspace_bytes(ctypes.byref(d)), x.device)
+    check(lib.efm_convb_mfm_bwd_weight(ctypes.byref(d), _p(x), _p(route), _p(dz), int(ways), int(bool(pool)), _p(dw), _p(dbias if want_bias else None),
+                                       int(bool(accumulate)), _p(ws), ctypes.c_size_t(ws.numel() * 4), _stream()), "efm_convb_mfm_bwd_weight")
+    return dw, (dbias if want_bias else None)
+
+
 # ---- Winograd F(2x2, 3x3) form of the 3x3 / pad 1 convolutions ----------------------------------------------------------
 PASS_FWD, PASS_FUSED, PASS_DGRAD, PASS_WGRAD, PASS_WINO_FWD, PASS_WINO_FUSED, PASS_WINO_DGRAD = range(7)
 

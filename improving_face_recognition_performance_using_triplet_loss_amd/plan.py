@@ -93,6 +93,7 @@ class Plan:
         self.steps = []
         self.params = collections.OrderedDict()
         self.rowpack = os.environ.get("EFM_ROWPACK", "1") != "0"
+        self.fused_wgrad = os.environ.get("EFM_FUSED_WGRAD", "1") != "0"   # bf16: weight gradient straight from dz + route bytes where it applies
         self._lower(outputs)
         self.fuse = (os.environ.get("EFM_FUSE", "1") != "0") if fuse is None else bool(fuse)
         self.fused = 0
@@ -495,12 +496,19 @@ class Plan:
                 d = st.desc
                 src = st.inputs[0]
                 bf = self.dtype == "bf16" and not st.f32
-                if st.epi is not None:  # gradient of the fused MFM (+ pool) epilogue -> full conv-output gradient
-                    dy = (ops.convb_mfm_pool_bwd if bf else ops.mfm_pool_bwd)(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
                 wgrad = ops.convb_bwd_weight if bf else ops.conv_bwd_weight
                 wname = st.pname + "_weight"
                 acc = wname in written
                 dwv, dbv = gv[wname], (None if st.no_bias else gv[st.pname + "_bias"])
+                wants_dx = src.needs_grad or (src.op in ("input", "rowpack") and need_input_grad)
+                if (st.epi is not None and bf and not wants_dx and st.residual is None and dy.dtype == torch.bfloat16
+                        and self.fused_wgrad and ops.convb_mfm_bwd_weight_supported(d, st.epi["ways"], st.epi["pool"])):
+                    # the only consumer of this layer's conv-output gradient is its own weight gradient (first convolution): the
+                    # kernel forms it in LDS from dz + the route bytes; nothing of it touches HBM
+                    route, dz, e = aux[st.index], dy, st.epi
+                    wgrad = lambda d_, x_, _dy, **kw: ops.convb_mfm_bwd_weight(d_, x_, route, dz, e["ways"], e["pool"], **kw)  # noqa: E731
+                elif st.epi is not None:  # gradient of the fused MFM (+ pool) epilogue -> full conv-output gradient
+                    dy = (ops.convb_mfm_pool_bwd if bf else ops.mfm_pool_bwd)(d, aux[st.index], dy, st.epi["ways"], st.epi["pool"])
                 if side is not None and red is not None and not bf:
                     # three streams: slabs of this layer on `side`; their reduction on `red`, i.e. under the NEXT layer's slabs
                     # kernel.  Two workspaces alternate; a workspace is written again only after the reduction that read it.

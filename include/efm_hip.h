@@ -168,6 +168,14 @@ int efm_convb_mfm_pool_bwd(const unsigned char* route, const void* dz, int dz_f3
 /* dw_packed / dbias are FLOAT, in the fp32 packed layout of efm_conv_bwd_weight */
 int efm_convb_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_packed, float* dbias, int accumulate,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Weight gradient of a convolution whose fused epilogue was bias -> MFM2 -> 2x2 max pooling (efm_convb_mfm_fwd, ways 2, pool 1), taken
+ * straight from the epilogue's output gradient dz [b][hout/2][wout/2][pad8(cout/2)] (bf16) and its route bytes: the conv-output
+ * gradient (ref: the backward of SliceChannel / maximum / Pooling, efm_symbol.py:62-64,76-78) is formed in LDS inside the kernel and
+ * never written to HBM.  For layers whose input needs no gradient (the first convolution) this replaces efm_convb_mfm_pool_bwd +
+ * efm_convb_bwd_weight; efm_convb_mfm_bwd_weight_supported says whether a layer qualifies.  Workspace: efm_convb_wgrad_workspace_bytes. */
+int efm_convb_mfm_bwd_weight_supported(const efm_conv_desc* d, int ways, int pool);
+int efm_convb_mfm_bwd_weight(const efm_conv_desc* d, const uint16_t* x, const unsigned char* route, const uint16_t* dz, int ways, int pool,
+                             float* dw_packed, float* dbias, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Layout conversion at the boundary (ImageRecordIter emits NCHW — ref: train_efm.py:179).

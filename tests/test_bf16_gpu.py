@@ -310,3 +310,27 @@ def test_convb_wgrad_of_the_rowpacked_first_convolution():
     dw_ref = np.stack([np.einsum("bchw,bnhw->nc", xp[:, :, a:a + h, :], dy) for a in range(5)], axis=2)[..., None]
     assert rel_err(ops.conv_unpack_weights(d, dw).cpu().numpy(), dw_ref) < 2e-5
     assert rel_err(db[:cout].cpu().numpy(), dy.sum(axis=(0, 2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 22, 37), (1, 112, 112), (3, 17, 16)])
+def test_convb_weight_gradient_straight_from_dz_and_route_bytes(shape):
+    """efm_convb_mfm_bwd_weight (first convolution, row-packed 5 x 1, 15 -> 96, MFM2 + 2x2 pooling): the conv-output gradient is formed
+    in LDS from dz + the route bytes instead of being written by efm_convb_mfm_pool_bwd and read back — same values in the same
+    accumulation order, so the result equals the two-kernel path BIT FOR BIT (odd maps: floor pooling drops the last row / column,
+    stage tiles overhang the image)."""
+    from improving_face_recognition_performance_using_triplet_loss_amd import ops
+    b, h, w = shape
+    cin, cout = 15, 96
+    d = ops.conv_desc(b, h, w, cin, cout, 5, 1, 2, 0)
+    assert ops.convb_mfm_bwd_weight_supported(d, 2, True) and not ops.convb_mfm_bwd_weight_supported(d, 3, True)
+    x = to_nhwc_bf16(ops, bf(rand((b, cin, h, w), 1)))
+    wb, _ = ops.convb_cast_weights(d, ops.conv_pack_weights(d, dev(rand((cout, cin, 5, 1), 2, 0.3))), need_dgrad=False)
+    bias = torch.zeros(d.n_pad16, device="cuda")
+    z, route = ops.convb_mfm_fwd(d, x, wb, bias, 2, 0, True)
+    dz = torch.as_tensor(rand(tuple(z.shape), 7), dtype=torch.float32).cuda().bfloat16()
+    dz[..., cout // 2:] = 0
+    dy = ops.convb_mfm_pool_bwd(d, route, dz, 2, True)
+    dw_ref, db_ref = ops.convb_bwd_weight(d, x, dy)
+    dw, db = ops.convb_mfm_bwd_weight(d, x, route, dz, 2, True)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    assert float(dw.abs().max()) > 0
