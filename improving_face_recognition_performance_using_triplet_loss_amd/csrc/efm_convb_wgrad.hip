@@ -89,7 +89,8 @@ __device__ __forceinline__ void wg2_body(const Wg2P& p, char* smem) {
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.dy), 0, p.y_bytes, 0x00020000);
 
   // ---- staging tables: piece e = tid + 512 j of an image -> what it loads, relative to the stage origin (fixed per thread)
-  constexpr int NJX = 5, NJY = EXPAND ? 1 : (12 * 32 * TH + W2_THREADS - 1) / W2_THREADS;
+  constexpr int NJX = (TN == 6 && WN == 2) ? 3 : 5;   // x pieces per thread: up to 1536 for the 12-chunk form (few input channels per tap group), 2560 else
+  constexpr int NJY = EXPAND ? 1 : (12 * 32 * TH + W2_THREADS - 1) / W2_THREADS;
   int xinfo[NJX], yinfo[NJY];  // hy | hx << 8 | channel offset << 16, or -1
 #pragma unroll
   for (int j = 0; j < NJX; ++j) {
@@ -265,14 +266,19 @@ __device__ __forceinline__ void wg2_body(const Wg2P& p, char* smem) {
           }
         }
       }
+      // k chunks: straight-line code, the fragment of chunk kt + 1 is read while the MFMAs of chunk kt run.  No per-chunk guard: a
+      // wave with fewer than TK chunks repeats its last one (the clamp in xlane) into accumulators that are never stored — a
+      // branch per chunk kept the compiler from moving any read ahead of the previous chunk's MFMAs: every chunk waited out its own
+      // LDS latency (measured: matrix pipe 28 % busy).  TK is picked per layer (ceil(chunks / 4)), so few slots are wasted.
+      const char* xb = xs + (wrow + 2 * s) * (p.hwp * 32);
+      bf16x8 b = tr_frag(xb + xlane[0][0], xb + xlane[0][1]);
 #pragma unroll
       for (int kt = 0; kt < TK; ++kt) {
-        if (kt < ktw) {  // wave-uniform
-          const char* base = xs + (wrow + 2 * s) * (p.hwp * 32);
-          const bf16x8 b = tr_frag(base + xlane[kt][0], base + xlane[kt][1]);
+        bf16x8 bn = b;
+        if (kt + 1 < TK) bn = tr_frag(xb + xlane[kt + 1][0], xb + xlane[kt + 1][1]);
 #pragma unroll
-          for (int nt = 0; nt < TN; ++nt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b, acc[nt][kt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < TN; ++nt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b, acc[nt][kt], 0, 0, 0);
+        b = bn;
       }
     }
   };
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) convb_wgrad2_k(const Wg2P p) {
 
 struct Wg2Plan {
   bool ok;
-  int cfg;  // 0: <6,7,2,4,2>   1: <4,9,2,4,2>   2: <6,5,1,1,1> (whole tile per wave, waves over the rows)
+  int cfg;  // 0: <6,TK,2,4,2>   1: <4,TK,2,4,2>   2: <6,5,1,1,1> (whole tile per wave, waves over the rows)
   int TN, TK, wm, th, nparts, tgroups, nch, cch, rows_g, hh, hwp, x_img_bytes, px, py, tiles_x, tiles_y, stages, stages_per_split, splits, kb_pad;
 };
 
@@ -393,6 +399,7 @@ Wg2Plan plan_wg2(const efm_conv_desc* d) {
     pl.rows_g = std::min(d->kh, cap / per_row);
     while (d->kh % pl.rows_g) --pl.rows_g;  // equal groups
     pl.tgroups = d->kh / pl.rows_g;
+    if (pl.cfg != 2) pl.TK = std::max(1, (pl.rows_g * per_row + 3) / 4);   // k chunks per wave: the instance without idle slots
     pl.th = pl.cfg == 2 ? 16 : 4;
     pl.hh = pl.th + pl.rows_g - 1;
     pl.hwp = 16 + d->kw - 1;
@@ -400,7 +407,7 @@ Wg2Plan plan_wg2(const efm_conv_desc* d) {
     pl.py = pl.nch * 32 * pl.th;
     pl.x_img_bytes = (pl.px * 16 + 1023) & ~1023;
     const int y_img_bytes = (pl.py * 16 + 1023) & ~1023;
-    fit = pl.x_img_bytes + y_img_bytes <= W2_STAGE_BYTES && pl.px <= 5 * W2_THREADS && pl.hh <= 255;
+    fit = pl.x_img_bytes + y_img_bytes <= W2_STAGE_BYTES && pl.px <= (pl.cfg == 0 ? 3 : 5) * W2_THREADS && pl.hh <= 255;
   }
   if (!fit) return pl;
   pl.tiles_x = (d->wout + 15) / 16;
@@ -441,10 +448,19 @@ int launch_wg2(const efm_conv_desc* d, const Wg2Plan& pl, const uint16_t* x, con
     hipLaunchKernelGGL((convb_wgrad2_k<6, 5, 1, 1, 1, true>), grid, dim3(W2_THREADS), 0, s, p);
   else if (pl.cfg == 2)
     hipLaunchKernelGGL((convb_wgrad2_k<6, 5, 1, 1, 1, false>), grid, dim3(W2_THREADS), 0, s, p);
-  else if (pl.cfg == 0)
-    hipLaunchKernelGGL((convb_wgrad2_k<6, 7, 2, 4, 2, false>), grid, dim3(W2_THREADS), 0, s, p);
-  else
-    hipLaunchKernelGGL((convb_wgrad2_k<4, 9, 2, 4, 2, false>), grid, dim3(W2_THREADS), 0, s, p);
+  else {
+#define EFM_W2_CASE(TN_, TK_) \
+  else if (pl.TN == TN_ && pl.TK == TK_) hipLaunchKernelGGL((convb_wgrad2_k<TN_, TK_, 2, 4, 2, false>), grid, dim3(W2_THREADS), 0, s, p);
+    if (false) {}
+    EFM_W2_CASE(6, 1) EFM_W2_CASE(6, 2) EFM_W2_CASE(6, 3) EFM_W2_CASE(6, 4) EFM_W2_CASE(6, 5) EFM_W2_CASE(6, 6) EFM_W2_CASE(6, 7)
+    EFM_W2_CASE(4, 1) EFM_W2_CASE(4, 2) EFM_W2_CASE(4, 3) EFM_W2_CASE(4, 4) EFM_W2_CASE(4, 5) EFM_W2_CASE(4, 6) EFM_W2_CASE(4, 7) EFM_W2_CASE(4, 8)
+    EFM_W2_CASE(4, 9)
+    else {
+      efm::set_error("convb_wgrad2: no instance for TN=%d TK=%d", pl.TN, pl.TK);
+      return EFM_E_INVALID;
+    }
+#undef EFM_W2_CASE
+  }
   return efm::check_launch("convb_wgrad2");
 }
 
