@@ -321,6 +321,8 @@ def host_loops(torch, device, cases=((128, 128, "train_efm.py / bench step: 128 
     from oracle import host_loops as H
     from improving_face_recognition_performance_using_triplet_loss_amd import data, ops, synth
     res = []
+    warm = torch.rand(16, 8)   # first-call costs of the torch CPU ops (dispatcher, thread pool) stay out of the timed loops
+    H.cosine_dist_loop(warm[:8], warm[8:], warm[:8], 8)
     for b, dim, what in cases:
         lab = (torch.arange(b, dtype=torch.int64) % max(b // 4, 2)).to(torch.float32)
         lab2 = torch.cat([lab, lab])

@@ -50,6 +50,10 @@ struct ConvP {
   int cn;  // fused epilogue with several channel blocks: block nb owns channels [nb*cn, nb*cn + cn) of EVERY slice
   int cpo;      // channel stride of the fused epilogue's output z and of the route bytes
   int out_f32;  // bf16 kernel only: write the fused epilogue's z as float (the layer that feeds the fp32 head)
+  // bf16 data gradient: K ordered (32-channel chunk, tap, channel) instead of (tap, channel): the 9 taps of a chunk are 9 consecutive
+  // K steps, so the shifted re-reads of the same 64 bytes of a pixel come back from L1 / L2 instead of HBM (see efm_convb_bwd_data)
+  int chunk_major;
+  unsigned magic_taps;  // ceil(2^32 / (kh*kw))
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -142,9 +146,17 @@ __device__ __forceinline__ void conv_fwd_body(const ConvP& p, float* smem) {
     return v ? (unsigned)((a_base[j] + doff) * EB) : EFM_OOB;
   };
   auto load_tile = [&](int t, int buf) {
-    const unsigned k = (unsigned)(t * KS + kc4);
-    const unsigned tap = __umulhi(k, p.magic_c);
-    const int c = (int)(k - tap * (unsigned)p.cin_p);
+    unsigned tap;
+    int c;
+    if (BF && p.chunk_major) {   // K step t = (chunk, tap): 32 channels of one tap
+      const unsigned chunk = __umulhi((unsigned)t, p.magic_taps);
+      tap = (unsigned)t - chunk * (unsigned)(p.kh * p.kw);
+      c = (int)chunk * 32 + kc4;
+    } else {
+      const unsigned k = (unsigned)(t * KS + kc4);
+      tap = __umulhi(k, p.magic_c);
+      c = (int)(k - tap * (unsigned)p.cin_p);
+    }
     // (kw == 1: ceil(2^32 / 1) does not fit the 32-bit multiplier — kx1 kernels, e.g. the row-packed first convolution)
     const unsigned kh_ = (p.kw == 1) ? tap : __umulhi(tap, p.magic_kw), kw_ = tap - kh_ * (unsigned)p.kw;
     const bool tap_ok = (int)tap < taps;
@@ -989,9 +1001,11 @@ FwdTiling fwd_tiling(long M, int n_pad16, int tune, int esize) {
 template <typename T>
 int run_fwd(const void* x, const void* w, const float* bias, const void* res, void* y, int batch,
             int hin, int win, int cin_p, int hout, int wout, int cout_p, int kh, int kw, int pad_h,
-            int pad_w, int n_pad16, int k_pad, int tune, hipStream_t s) {
+            int pad_w, int n_pad16, int k_pad, int tune, hipStream_t s, int chunk_major = 0) {
   constexpr int KS = 64 / (int)sizeof(T);  // K elements per LDS row / K step
   ConvP p;
+  p.chunk_major = chunk_major;
+  p.magic_taps = (unsigned)((0x100000000ULL + (unsigned)(kh * kw) - 1) / (unsigned)(kh * kw));
   p.x = x; p.w = w; p.bias = bias; p.res = res; p.y = y;
   p.M = batch * hout * wout;
   p.hin = hin; p.win = win; p.cin_p = cin_p;
@@ -1111,6 +1125,14 @@ __host__ __device__ __forceinline__ bool fc_shaped(const efm_conv_desc& d) {
   return d.hout == 1 && d.wout == 1 && d.pad_h == 0 && d.pad_w == 0 && d.kh == d.hin && d.kw == d.win && d.kh * d.kw > 1;
 }
 
+// The bf16 data gradient of a k x k convolution (k > 1) whose output channels fill whole 32-channel K steps runs with its K ordered
+// (chunk, tap, channel): measured on conv2 (192 -> 48 back to the input, 56x56, 512 images) the tap-major order re-fetched the 616 MB
+// gradient TEN times from HBM (FETCH_SIZE 6.2 GB per launch: the 9 shifted reads of a pixel's 64 bytes were a whole pass over the
+// channels apart, and the blocks resident on an XCD cover far more than its 4 MB of L2) — the kernel ran at HBM speed, 7.3 TB/s.
+__host__ __device__ __forceinline__ bool dgrad_chunk_major(const efm_conv_desc& d) {
+  return !fc_shaped(d) && d.kh * d.kw > 1 && (pad8(d.cout) & 31) == 0;
+}
+
 __global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restrict__ w32, __bf16* __restrict__ wb,
                                                            __bf16* __restrict__ wdb, efm_conv_desc d, long nf, long nd) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1134,7 +1156,12 @@ __global__ void __launch_bounds__(256) cast_weights_bf16_k(const float* __restri
     const long e = i - nf;
     const int kp = pad32(taps * cout8);
     const int ci = (int)(e / kp), k = (int)(e - (long)ci * kp);
-    const int tap = k / cout8, co = k - tap * cout8;
+    int tap = k / cout8, co = k - tap * cout8;
+    if (dgrad_chunk_major(d)) {   // k = ((chunk * taps) + tap) * 32 + channel of the chunk
+      const int t = k >> 5, chunk = t / taps;
+      tap = t - chunk * taps;
+      co = chunk * 32 + (k & 31);
+    }
     float v = 0.f;
     if (ci < d.cin && tap < taps && co < d.cout) {
       const int fkh = tap / d.kw, fkw = tap - fkh * d.kw;
@@ -1558,6 +1585,7 @@ int efm_conv_mfm_fwd(const efm_conv_desc* d, const float* x, const float* w_pack
   p.n_pad16 = d->n_pad16; p.k_pad = d->k_pad; p.ksteps = d->k_pad / 16;
   p.nblocks = nsplit;
   p.cn = cn;
+  p.chunk_major = 0; p.magic_taps = 0;
   p.cpo = efm_pad4((ways == 3) ? 2 * cs_all : cs_all);
   p.out_f32 = 1;
   p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
@@ -1756,7 +1784,7 @@ int efm_convb_bwd_data(const efm_conv_desc* d, const uint16_t* dy, const uint16_
   }
   return run_fwd<__bf16>(dy, wdb, nullptr, add, dx, d->batch, d->hout, d->wout, pad8(d->cout), d->hin, d->win, pad8(d->cin), d->kh, d->kw,
                          d->kh - 1 - d->pad_h, d->kw - 1 - d->pad_w, d->dn_pad16, pad32(d->kh * d->kw * pad8(d->cout)), d->tune_dgrad,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, dgrad_chunk_major(*d) ? 1 : 0);
 }
 
 int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t* wb, const float* bias, void* z, unsigned char* route,
@@ -1787,6 +1815,7 @@ int efm_convb_mfm_fwd(const efm_conv_desc* d, const uint16_t* x, const uint16_t*
   p.kh = d->kh; p.kw = d->kw; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.n_pad16 = d->n_pad16; p.k_pad = kp; p.ksteps = kp / 32;
   p.nblocks = nsplit; p.cn = cn;
+  p.chunk_major = 0; p.magic_taps = 0;
   p.cpo = out_f32 ? efm_pad4(co) : pad8(co);
   p.out_f32 = out_f32 ? 1 : 0;
   p.route = route; p.cout = d->cout; p.ways = ways; p.order = order; p.pool = pool ? 1 : 0;
