@@ -30,11 +30,12 @@ def clean(k):
 
 
 def stats_table(path, top=22, steps=7):
+    """steps = None: total ms of the run (the fp32 run also holds the roofline probe's isolated launches, so a per-step figure would mislead)."""
     rows = list(csv.DictReader(open(path)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    out = ["| % | ms / step | calls | avg us | kernel |", "|---|---|---|---|---|"]
+    out = ["| % | %s | calls | avg us | kernel |" % ("ms / step" if steps else "total ms"), "|---|---|---|---|---|"]
     for r in rows[:top]:
-        out.append("| %.2f | %.3f | %s | %.1f | `%s` |" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6 / steps, r["Calls"],
+        out.append("| %.2f | %.3f | %s | %.1f | `%s` |" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6 / (steps or 1), r["Calls"],
                                                          float(r["AverageNs"]) / 1e3, clean(r["Name"])[:120]))
     return rows, total, out
 
@@ -46,7 +47,7 @@ def bench_line(fn):
 lines = ["# round 3 — profiles of one MI355X (rocprofv3; un-profiled figures are in BENCH_r03 / DESIGN.md)", ""]
 stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, "profiles/%s_kernel_stats.csv" % name)
-rows, total, table = stats_table(stats)
+rows, total, table = stats_table(stats, steps=None)
 bench = bench_line("bench_line.json")
 roof = bench["roofline"]
 KEY = open(os.path.join(src, "dominant.txt")).read().strip()
