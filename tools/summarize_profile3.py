@@ -33,7 +33,7 @@ def stats_table(path, top=22, steps=7):
     """steps = None: total ms of the run (the fp32 run also holds the roofline probe's isolated launches, so a per-step figure would mislead)."""
     rows = list(csv.DictReader(open(path)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    out = ["| % | %s | calls | avg us | kernel |" % ("ms / step" if steps else "total ms"), "|---|---|---|---|---|"]
+    out = ["| %% | %s | calls | avg us | kernel |" % ("ms / step" if steps else "total ms"), "|---|---|---|---|---|"]
     for r in rows[:top]:
         out.append("| %.2f | %.3f | %s | %.1f | `%s` |" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6 / (steps or 1), r["Calls"],
                                                          float(r["AverageNs"]) / 1e3, clean(r["Name"])[:120]))
