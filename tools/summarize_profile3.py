@@ -135,6 +135,12 @@ if rowsb:
         conf = mean(c["SQ_LDS_BANK_CONFLICT"]) / mean(c["SQ_LDS_IDX_ACTIVE"]) if c["SQ_LDS_IDX_ACTIVE"] and mean(c["SQ_LDS_IDX_ACTIVE"]) > 0 else float("nan")
         lines.append("| `%s` | %d | %.1f | %.1f | %.1f | %.3f | %.3f |" % (k[:100], len(durs.get(k, [])), mean(durs.get(k, [])), mean(c["FETCH_SIZE"]) * 2048 / 1e6,
                                                                         mean(c["WRITE_SIZE"]) * 1024 / 1e6, busy, conf))
+if rowsb:
+    lines += ["", "Legend (rocprofv3 leaves some bf16 instance names mangled): `conv_fwd_kI__bf16Li<MT>ELi<NT>ELb1ELi<EPI>E` = `conv_fwd_k<__bf16, MT, NT, true, EPI>` "
+              "(EPI 1 = fused bias + MFM2 (+ pool) forward, EPI 0 = plain forward / data gradient): `Li2ELi13ELb1ELi1E` = the fused forwards of conv2 / conv3, "
+              "`Li2ELi13ELb1ELi0E` = their plain forwards (timed by conv_bench beside the fused ones), `Li2ELi6ELb1ELi0E` = conv3's data gradient (N = 96), the "
+              "garbled `conv_fwd_k<bool _Accum, ..., E, 0>` = `<__bf16, 2, 3, true, 0>` = conv2's data gradient (N = 48).  Before the chunk-major K order "
+              "(first profile of the round, `gpurun_out/r3prof`) those two data gradients read 6 203 MB and 2 800 MB from HBM per launch at 0.135 / 0.246 busy."]
 for fn, title in (("per_layer.log", "fp32 EFM-29, benchmarked kernel selection, each launch alone (tools/conv_bench.py --tuned)"),
                   ("per_layer_lc9.log", "bf16 LightCNN-9, 512 images (tools/conv_bench.py --net lightcnn9 --dtype bf16)")):
     f = os.path.join(src, fn)
